@@ -1,0 +1,185 @@
+/*
+ * mgrt.h -- C ABI of libmgrt.so, the MI355X (gfx950) HIP runtime under the multigrid solver.
+ *
+ * This is the drop-in boundary: the C++ classes that mirror the reference's public interface
+ * (Buffer2D/3D, BorderHandler2D/3D, MultigridSolver2D/3D, the free norm functions) call nothing
+ * but the functions below, where the reference called OpenCL (cl::Buffer, cl::Kernel::setArg,
+ * cl::CommandQueue::enqueueNDRangeKernel).  Plain pointers and sizes only; every function returns
+ * 0 on success, a positive hipError_t value when HIP failed, or a negative MGRT_E_* code when an
+ * argument was rejected; mgrt_last_error() describes the last failure of the calling thread.
+ * Nothing throws across this boundary.  One host thread per stream, as in the reference (one
+ * in-order queue per solver, multigridsolver3D.cpp:36).
+ *
+ * Fields are stored x fastest: element (x,y,z) of a field lives at  x + pitch*y + slab*z
+ * (the reference's dense layout, multi_array.h:36,75, is pitch = nx, slab = nx*ny).  2D fields
+ * have nz = 1.  Every kernel exists for float (_f32) and double (_f64), the two settings of the
+ * reference's real.cl:2-18.  Kernel calls are asynchronous on the given stream.
+ *
+ * Numerics contract: every kernel evaluates the reference's expressions in the reference's
+ * operation order, with the reference's mixed precision (bare literals are double), without
+ * fused multiply-add.  The 3D smoother, whose colouring ignores z (mg_1.cl:98), uses the serial
+ * NDRange schedule: within one colour pass each (x,y) column is relaxed in ascending z, so
+ * u_new[z] sees u_new[z-1] and u_old[z+1].
+ */
+#ifndef MGRT_H
+#define MGRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int mgrt_status;
+typedef void *mgrt_stream; /* a hipStream_t; NULL is the default stream */
+
+enum {
+    MGRT_OK = 0,
+    MGRT_E_INVALID = -1,     /* bad argument (null pointer, extent, range, alignment) */
+    MGRT_E_UNSUPPORTED = -2, /* valid request the library does not implement */
+    MGRT_E_NOT_INIT = -3,    /* mgrt_init has not been called */
+    MGRT_E_NO_DEVICE = -4    /* no gfx950 device visible */
+};
+
+/* cell classes: the values of BorderHandler3D::CellType (multigridsolver3D.h:28), which stand
+ * for the NaN-encoded normals of the reference's device Cell (mg_1.cl:5-26, mg_0.cl:5-26) */
+enum { MGRT_CELL_INNER = 0, MGRT_CELL_OUTER = 1, MGRT_CELL_DIRICHLET = 2, MGRT_CELL_NEUMANN = 3 };
+
+/*
+ * One level's geometry and domain description.  Replaces the (Cell buffer, int4 size) pair every
+ * reference kernel receives (mg_1.cl:91-96) and the per-extent cell maps the border handler
+ * generates and caches (rectangularborderhandler.cpp:34-40,46-68,77-114).
+ *
+ *  cells != NULL : device byte map, one MGRT_CELL_* value per point, laid out with the same
+ *                  pitch and slab (in bytes) as the fields.  Any domain a BorderHandler can
+ *                  describe.  Inner cells must not lie on a face of the global grid.
+ *  cells == NULL : analytic box, no memory traffic: the six faces carry face[] =
+ *                  {x-lo, x-hi, y-lo, y-hi, z-lo, z-hi} types and every other point is inner.
+ *                  On shared edges the reference's fill order decides
+ *                  (rectangularborderhandler.cpp:59-62,103-108): 3D y faces over x faces over
+ *                  z faces, 2D x faces over y faces.
+ *
+ *  y0, gny describe a y-slab of a larger grid for multi-GPU runs: the arrays hold rows
+ *  [y0, y0+ny) of a grid with gny rows.  Colours, cell classes and coarse/fine index relations
+ *  are evaluated with the global row y0 + y.  A whole grid is y0 = 0, gny = ny.
+ */
+typedef struct mgrt_grid {
+    int dim;        /* 2 or 3 */
+    int nx, ny, nz; /* extents of the arrays (nz = 1 when dim == 2) */
+    int pitch;      /* elements between rows, >= nx */
+    long long slab; /* elements between z planes, >= pitch*ny */
+    int y0, gny;    /* first global row held, global row count */
+    const unsigned char *cells;
+    int face[6];
+} mgrt_grid;
+
+/* ---- runtime: replaces CLContextLoader (clcontextloader.cpp:29-80) and cl::Buffer / queue use
+ * in buffer.h:39-45,61-79 and multigridsolver3D.h:68 ------------------------------------------ */
+mgrt_status mgrt_init(int device);                  /* select device, allocate reduction scratch */
+mgrt_status mgrt_shutdown(void);
+const char *mgrt_last_error(void);
+mgrt_status mgrt_device_name(char *buf, int len);   /* clcontextloader.cpp:59 prints the device */
+mgrt_status mgrt_alloc(void **ptr, size_t bytes);   /* cl::Buffer ctor, buffer.h:39-41 */
+mgrt_status mgrt_free(void *ptr);
+mgrt_status mgrt_upload(void *dst, const void *src, size_t bytes, mgrt_stream s); /* COPY_HOST_PTR */
+mgrt_status mgrt_download(void *dst, const void *src, size_t bytes, mgrt_stream s); /* blocking, buffer.h:77 */
+mgrt_status mgrt_stream_create(mgrt_stream *s);     /* cl::CommandQueue ctor, multigridsolver3D.cpp:36 */
+mgrt_status mgrt_stream_destroy(mgrt_stream s);
+mgrt_status mgrt_sync(mgrt_stream s);               /* queue.finish(), multigridsolver3D.h:68 */
+mgrt_status mgrt_zero(void *ptr, size_t bytes, mgrt_stream s); /* zero_memory, common_kernels.cl:6-10 */
+
+/* Fill a host byte map for a box with the given face types (the generator behind cells == NULL),
+ * replaces genBuffer (rectangularborderhandler.cpp:46-68,89-114).  Host memory, dense layout. */
+mgrt_status mgrt_box_cells_host(int dim, int nx, int ny, int nz, const int face[6], unsigned char *cells);
+
+#define MGRT_DECLARE_KERNELS(R, S)                                                                 \
+    /* One colour pass of the weighted Gauss-Seidel smoother, in place.  Replaces                 \
+       iteration_kernel (mg_1.cl:91-104, mg_0.cl:86-98) as launched by smoother_iterate           \
+       (multigridsolver3D.cpp:111-132).  Colour = (x + y + odd) % 2.  Relaxes planes z < zcount   \
+       (the reference passes ceil(nz/2), multigridsolver3D.cpp:121) and rows ylo <= y < yhi. */   \
+    mgrt_status mgrt_smooth_pass##S(const mgrt_grid *g, R *u, const R *f, R omega, int odd,        \
+                                    int zcount, int ylo, int yhi, mgrt_stream s);                  \
+    /* `iters` full iterations (colour 0 then colour 1 each) with the same results as 2*iters      \
+       calls of mgrt_smooth_pass; free to fuse them.  Replaces the loop of smoother_iterate. */   \
+    mgrt_status mgrt_smooth##S(const mgrt_grid *g, R *u, const R *f, R omega, int iters,           \
+                               int zcount, mgrt_stream s);                                         \
+    /* r = f - A u on inner cells, f - u on Dirichlet cells; outer and Neumann cells of r are     \
+       left untouched, or set to 0 when zero_unwritten != 0.  Replaces residual_kernel            \
+       (mg_1.cl:111-133, mg_0.cl:105-126).  norm2 (device, may be NULL) receives sum(r*r) over    \
+       the cells written, accumulated in double. */                                               \
+    mgrt_status mgrt_residual##S(const mgrt_grid *g, R *r, const R *u, const R *f,                 \
+                                 int zero_unwritten, double *norm2, int ylo, int yhi,              \
+                                 mgrt_stream s);                                                   \
+    /* Full-weighting restriction with injection next to border cells.  Replaces                  \
+       reduction_kernel (mg_1.cl:146-190, mg_0.cl:139-157).  Coarse rows cylo <= j < cyhi. */     \
+    mgrt_status mgrt_restrict##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc,            \
+                                 const R *rf, int cylo, int cyhi, mgrt_stream s);                  \
+    /* out = u + 4*P(e), P bi/trilinear, injection on border cells; out may alias u.  Replaces    \
+       residual_correct_kernel (mg_1.cl:200-233, mg_0.cl:167-194). */                             \
+    mgrt_status mgrt_correct##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *out,            \
+                                const R *u, const R *e, int ylo, int yhi, mgrt_stream s);          \
+    /* out = P(c).  Replaces prolongation_kernel (mg_1.cl:236-267, mg_0.cl:197-222). */           \
+    mgrt_status mgrt_prolong##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *out,            \
+                                const R *c, int ylo, int yhi, mgrt_stream s);                      \
+    /* clear outer cells.  Replaces zero_out (mg_1.cl:269-275, mg_0.cl:224-230). */               \
+    mgrt_status mgrt_zero_outside##S(const mgrt_grid *g, R *u, mgrt_stream s);                     \
+    /* out = a - b over the grid.  Replaces Diff (common_kernels.cl:56-62, auxiliary.h:96-109). */ \
+    mgrt_status mgrt_diff##S(const mgrt_grid *g, R *out, const R *a, const R *b, mgrt_stream s);   \
+    /* Exact norms over rows ylo..yhi: sum of squares / max |x| accumulated in double into a      \
+       device scalar, deterministic (fixed two-stage reduction, no atomics).  These are the       \
+       engine's norms; the reference's lossy tree is below. */                                    \
+    mgrt_status mgrt_sumsq##S(const mgrt_grid *g, const R *x, double *out, int ylo, int yhi,       \
+                              mgrt_stream s);                                                      \
+    mgrt_status mgrt_maxabs##S(const mgrt_grid *g, const R *x, double *out, int ylo, int yhi,      \
+                               mgrt_stream s);                                                     \
+    /* Blocking norms with the reference's exact behaviour: element-wise square, then the /4      \
+       reduction tree that accumulates in R and drops up to 3 tail elements per level             \
+       (auxiliary.cpp:119-173, auxiliary.h:72-82, common_kernels.cl:13-53); sqrt on the host.     \
+       Dense arrays only (pitch == nx, slab == nx*ny). */                                         \
+    mgrt_status mgrt_l2norm_reftree##S(const R *x, long long n, R *result, mgrt_stream s);         \
+    mgrt_status mgrt_linfnorm_reftree##S(const R *x, long long n, R *result, mgrt_stream s);
+
+MGRT_DECLARE_KERNELS(float, _f32)
+MGRT_DECLARE_KERNELS(double, _f64)
+
+/*
+ * Pre-planned V-cycle: the level hierarchy of MultigridSolver{2,3}D::iterate
+ * (multigridsolver3D.cpp:41-80: extents n -> (n+1)/2 while every extent > 3) with all work
+ * arrays allocated once, where the reference allocates three buffers per level per call
+ * (multigridsolver3D.cpp:53-55).  The correction is applied in place, which gives the same
+ * values as the reference's out-of-place kernel plus handle swap (multigridsolver3D.cpp:70-72).
+ * Residual cells the reference never writes (outer/Neumann) and then restricts from
+ * uninitialised memory are defined as 0.
+ */
+typedef struct mgrt_plan mgrt_plan;
+
+typedef struct mgrt_plan_desc {
+    int dim;          /* 2 or 3 */
+    int nx, ny, nz;   /* finest extents */
+    int elem_size;    /* 4 = float, 8 = double */
+    int face[6];      /* box face types, used for every level without an uploaded cell map */
+    int zfull;        /* 0: reference z range ceil(nz/2) in the 3D smoother; 1: all planes */
+    int use_graph;    /* replay each distinct cycle from a captured hipGraph */
+} mgrt_plan_desc;
+
+mgrt_status mgrt_plan_create(mgrt_plan **plan, const mgrt_plan_desc *desc, mgrt_stream s);
+mgrt_status mgrt_plan_destroy(mgrt_plan *plan);
+int mgrt_plan_levels(const mgrt_plan *plan);
+/* extents of a level (0 = finest) */
+mgrt_status mgrt_plan_level_dims(const mgrt_plan *plan, int level, int *nx, int *ny, int *nz);
+/* install a dense host byte map (values MGRT_CELL_*) for one level; replaces the analytic box */
+mgrt_status mgrt_plan_set_cells(mgrt_plan *plan, int level, const unsigned char *host_cells);
+/* `ncycles` times iterate(u, f, omega, a1, a2, v) on dense device arrays u (in/out) and f.
+ * res_hist (host, may be NULL) receives ncycles+1 values: ||f - A u||_2 before the first cycle
+ * and after each one (exact norm, double).  Blocking only when res_hist != NULL. */
+mgrt_status mgrt_plan_vcycle(mgrt_plan *plan, void *u, const void *f, double omega, int a1, int a2,
+                             int v, int ncycles, double *res_hist);
+/* fmg(f, ...) of multigridsolver3D.cpp:82-109 into u_out (dense device array) */
+mgrt_status mgrt_plan_fmg(mgrt_plan *plan, void *u_out, const void *f, double omega, int a1,
+                          int a2, int v, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGRT_H */

@@ -1,0 +1,288 @@
+"""ctypes binding of libmgrt.so (the C ABI declared in include/mgrt.h).
+
+This is plumbing for tests and bench.py: device memory comes from torch tensors, whose data
+pointers and stream handle are passed straight through the C ABI.  There is no fallback: when the
+shared library is missing, or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmgrt.so")
+
+INNER, OUTER, DIRICHLET, NEUMANN = 0, 1, 2, 3
+ALL_DIRICHLET = (DIRICHLET,) * 6
+
+
+class MgrtError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("mgrt status %d: %s" % (status, message))
+        self.status = status
+
+
+class Grid(C.Structure):
+    """mgrt_grid"""
+    _fields_ = [
+        ("dim", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+        ("pitch", C.c_int), ("slab", C.c_longlong),
+        ("y0", C.c_int), ("gny", C.c_int),
+        ("cells", C.c_void_p), ("face", C.c_int * 6),
+    ]
+
+
+class PlanDesc(C.Structure):
+    """mgrt_plan_desc"""
+    _fields_ = [
+        ("dim", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+        ("elem_size", C.c_int), ("face", C.c_int * 6), ("zfull", C.c_int), ("use_graph", C.c_int),
+    ]
+
+
+# every symbol include/mgrt.h declares; checked by the CPU test-suite against the header
+_KERNELS = ["smooth_pass", "smooth", "residual", "restrict", "correct", "prolong", "zero_outside",
+            "diff", "sumsq", "maxabs", "l2norm_reftree", "linfnorm_reftree"]
+_RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "upload", "download",
+            "stream_create", "stream_destroy", "sync", "zero", "box_cells_host",
+            "plan_create", "plan_destroy", "plan_levels", "plan_level_dims", "plan_set_cells",
+            "plan_vcycle", "plan_fmg"]
+SYMBOLS = ["mgrt_" + n for n in _RUNTIME] + ["mgrt_%s_%s" % (k, s) for k in _KERNELS for s in ("f32", "f64")]
+
+_lib = None
+
+
+def load():
+    """Load libmgrt.so and declare prototypes.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+                          % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    i, p, ll, d = C.c_int, C.c_void_p, C.c_longlong, C.c_double
+    G = C.POINTER(Grid)
+    lib.mgrt_last_error.restype = C.c_char_p
+    lib.mgrt_last_error.argtypes = []
+    sig = {
+        "init": [i], "shutdown": [], "device_name": [C.c_char_p, i],
+        "alloc": [C.POINTER(p), C.c_size_t], "free": [p],
+        "upload": [p, p, C.c_size_t, p], "download": [p, p, C.c_size_t, p],
+        "stream_create": [C.POINTER(p)], "stream_destroy": [p], "sync": [p], "zero": [p, C.c_size_t, p],
+        "box_cells_host": [i, i, i, i, C.POINTER(i), p],
+        "plan_create": [C.POINTER(p), C.POINTER(PlanDesc), p], "plan_destroy": [p],
+        "plan_level_dims": [p, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)],
+        "plan_set_cells": [p, i, p],
+        "plan_vcycle": [p, p, p, d, i, i, i, i, C.POINTER(d)],
+        "plan_fmg": [p, p, p, d, i, i, i, i],
+    }
+    for name, args in sig.items():
+        f = getattr(lib, "mgrt_" + name)
+        f.restype = i
+        f.argtypes = args
+    lib.mgrt_plan_levels.restype = i
+    lib.mgrt_plan_levels.argtypes = [p]
+    for S, r in (("f32", C.c_float), ("f64", C.c_double)):
+        ksig = {
+            "smooth_pass": [G, p, p, r, i, i, i, i, p],
+            "smooth": [G, p, p, r, i, i, p],
+            "residual": [G, p, p, p, i, p, i, i, p],
+            "restrict": [G, G, p, p, i, i, p],
+            "correct": [G, G, p, p, p, i, i, p],
+            "prolong": [G, G, p, p, i, i, p],
+            "zero_outside": [G, p, p],
+            "diff": [G, p, p, p, p],
+            "sumsq": [G, p, p, i, i, p],
+            "maxabs": [G, p, p, i, i, p],
+            "l2norm_reftree": [p, ll, C.POINTER(r), p],
+            "linfnorm_reftree": [p, ll, C.POINTER(r), p],
+        }
+        for name, args in ksig.items():
+            f = getattr(lib, "mgrt_%s_%s" % (name, S))
+            f.restype = i
+            f.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != 0:
+        raise MgrtError(status, load().mgrt_last_error().decode())
+
+
+_initialised = None
+
+
+def init(device=0):
+    """mgrt_init on the given device (idempotent for the same device)."""
+    global _initialised
+    check(load().mgrt_init(device))
+    _initialised = device
+
+
+def grid(shape, cells=None, faces=ALL_DIRICHLET, y0=0, gny=None, pitch=None, slab=None):
+    """Build an mgrt_grid for arrays of numpy/torch shape (nz, ny, nx) or (ny, nx).
+
+    `cells` is a device tensor (uint8, same shape) or None for the analytic box with `faces`.
+    Keeps a reference to `cells` on the returned struct so the memory outlives the call.
+    """
+    g = Grid()
+    if len(shape) == 3:
+        g.dim, g.nz, g.ny, g.nx = 3, shape[0], shape[1], shape[2]
+    else:
+        g.dim, g.nz, g.ny, g.nx = 2, 1, shape[0], shape[1]
+    g.pitch = g.nx if pitch is None else pitch
+    g.slab = g.pitch * g.ny if slab is None else slab
+    g.y0 = y0
+    g.gny = g.ny if gny is None else gny
+    g.cells = None if cells is None else cells.data_ptr()
+    g._keep = cells
+    g.face = (C.c_int * 6)(*faces)
+    return g
+
+
+def _suffix(t):
+    import torch
+    return {torch.float32: "f32", torch.float64: "f64"}[t.dtype]
+
+
+def _stream(stream):
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    return C.c_void_p(stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _fn(name, t):
+    return getattr(load(), "mgrt_%s_%s" % (name, _suffix(t)))
+
+
+# ---- kernel wrappers over torch tensors --------------------------------------------------------
+def smooth_pass(g, u, f, omega, odd, zcount=None, ylo=0, yhi=None, stream=None):
+    check(_fn("smooth_pass", u)(C.byref(g), _p(u), _p(f), omega, odd, g.nz if zcount is None else zcount,
+                                ylo, g.ny if yhi is None else yhi, _stream(stream)))
+
+
+def smooth(g, u, f, omega, iters, zcount=None, stream=None):
+    check(_fn("smooth", u)(C.byref(g), _p(u), _p(f), omega, iters, g.nz if zcount is None else zcount,
+                           _stream(stream)))
+
+
+def residual(g, r, u, f, zero_unwritten=False, norm2=None, ylo=0, yhi=None, stream=None):
+    check(_fn("residual", u)(C.byref(g), _p(r), _p(u), _p(f), int(zero_unwritten), _p(norm2), ylo,
+                             g.ny if yhi is None else yhi, _stream(stream)))
+
+
+def restrict(gf, gc, rc, rf, cylo=0, cyhi=None, stream=None):
+    check(_fn("restrict", rf)(C.byref(gf), C.byref(gc), _p(rc), _p(rf), cylo, gc.ny if cyhi is None else cyhi,
+                              _stream(stream)))
+
+
+def correct(gf, gc, out, u, e, ylo=0, yhi=None, stream=None):
+    check(_fn("correct", u)(C.byref(gf), C.byref(gc), _p(out), _p(u), _p(e), ylo, gf.ny if yhi is None else yhi,
+                            _stream(stream)))
+
+
+def prolong(gf, gc, out, c, ylo=0, yhi=None, stream=None):
+    check(_fn("prolong", out)(C.byref(gf), C.byref(gc), _p(out), _p(c), ylo, gf.ny if yhi is None else yhi,
+                              _stream(stream)))
+
+
+def zero_outside(g, u, stream=None):
+    check(_fn("zero_outside", u)(C.byref(g), _p(u), _stream(stream)))
+
+
+def diff(g, out, a, b, stream=None):
+    check(_fn("diff", a)(C.byref(g), _p(out), _p(a), _p(b), _stream(stream)))
+
+
+def sumsq(g, x, out, ylo=0, yhi=None, stream=None):
+    check(_fn("sumsq", x)(C.byref(g), _p(x), _p(out), ylo, g.ny if yhi is None else yhi, _stream(stream)))
+
+
+def maxabs(g, x, out, ylo=0, yhi=None, stream=None):
+    check(_fn("maxabs", x)(C.byref(g), _p(x), _p(out), ylo, g.ny if yhi is None else yhi, _stream(stream)))
+
+
+def l2norm_reftree(x, stream=None):
+    r = (C.c_float if _suffix(x) == "f32" else C.c_double)()
+    check(_fn("l2norm_reftree", x)(_p(x), x.numel(), C.byref(r), _stream(stream)))
+    return r.value
+
+
+def linfnorm_reftree(x, stream=None):
+    r = (C.c_float if _suffix(x) == "f32" else C.c_double)()
+    check(_fn("linfnorm_reftree", x)(_p(x), x.numel(), C.byref(r), _stream(stream)))
+    return r.value
+
+
+def box_cells_host(shape, faces=ALL_DIRICHLET):
+    import numpy as np
+    cells = np.empty(shape, dtype=np.uint8)
+    if len(shape) == 3:
+        dim, nz, ny, nx = 3, *shape
+    else:
+        dim, nz, (ny, nx) = 2, 1, shape
+    check(load().mgrt_box_cells_host(dim, nx, ny, nz, (C.c_int * 6)(*faces), cells.ctypes.data_as(C.c_void_p)))
+    return cells
+
+
+class Plan:
+    """mgrt_plan: pre-allocated hierarchy; iterate/mg/fmg of MultigridSolver{2,3}D on device arrays."""
+
+    def __init__(self, shape, dtype, faces=ALL_DIRICHLET, zfull=False, use_graph=False, stream=None):
+        import torch
+        d = PlanDesc()
+        if len(shape) == 3:
+            d.dim, d.nz, d.ny, d.nx = 3, shape[0], shape[1], shape[2]
+        else:
+            d.dim, d.nz, d.ny, d.nx = 2, 1, shape[0], shape[1]
+        d.elem_size = {torch.float32: 4, torch.float64: 8}[dtype]
+        d.face = (C.c_int * 6)(*faces)
+        d.zfull = int(zfull)
+        d.use_graph = int(use_graph)
+        self.shape, self.dtype = tuple(shape), dtype
+        self._h = C.c_void_p()
+        check(load().mgrt_plan_create(C.byref(self._h), C.byref(d), _stream(stream)))
+
+    def close(self):
+        if self._h:
+            check(load().mgrt_plan_destroy(self._h))
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def levels(self):
+        return load().mgrt_plan_levels(self._h)
+
+    def level_shape(self, level):
+        nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
+        check(load().mgrt_plan_level_dims(self._h, level, C.byref(nx), C.byref(ny), C.byref(nz)))
+        return (nz.value, ny.value, nx.value) if len(self.shape) == 3 else (ny.value, nx.value)
+
+    def set_cells(self, level, host_cells):
+        import numpy as np
+        c = np.ascontiguousarray(host_cells, dtype=np.uint8)
+        assert c.shape == self.level_shape(level)
+        check(load().mgrt_plan_set_cells(self._h, level, c.ctypes.data_as(C.c_void_p)))
+
+    def vcycle(self, u, f, omega=1.0, a1=2, a2=2, v=1, ncycles=1, history=False):
+        """ncycles x iterate(u, f, ...).  Returns the residual history (ncycles+1 floats) or None."""
+        assert u.is_contiguous() and f.is_contiguous() and u.dtype == self.dtype and f.dtype == self.dtype
+        assert tuple(u.shape) == self.shape and tuple(f.shape) == self.shape
+        hist = (C.c_double * (ncycles + 1))() if history else None
+        check(load().mgrt_plan_vcycle(self._h, _p(u), _p(f), omega, a1, a2, v, ncycles, hist))
+        return list(hist) if history else None
+
+    def fmg(self, u_out, f, omega=1.0, a1=3, a2=3, v=2, iters=3):
+        assert u_out.is_contiguous() and f.is_contiguous()
+        assert tuple(u_out.shape) == self.shape and tuple(f.shape) == self.shape
+        check(load().mgrt_plan_fmg(self._h, _p(u_out), _p(f), omega, a1, a2, v, iters))

@@ -1,0 +1,46 @@
+// mgrt_internal.h -- shared declarations of the libmgrt.so translation units (not installed).
+#ifndef MGRT_INTERNAL_H
+#define MGRT_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include "mgrt.h"
+
+namespace mgrt {
+
+// Record a failure message for mgrt_last_error() and return `code`.
+mgrt_status fail(mgrt_status code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define MGRT_HIP(expr)                                                                             \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return ::mgrt::fail((mgrt_status)e_, "%s: %s", #expr, hipGetErrorString(e_));          \
+    } while (0)
+
+#define MGRT_REQUIRE(cond, ...)                                                                    \
+    do {                                                                                           \
+        if (!(cond))                                                                               \
+            return ::mgrt::fail(MGRT_E_INVALID, __VA_ARGS__);                                      \
+    } while (0)
+
+// Per-device state created by mgrt_init.
+struct Runtime {
+    bool ready = false;
+    int device = -1;
+    int num_cu = 0;
+    double *partials = nullptr; // reduction scratch: one double per block
+    size_t partials_cap = 0;    // entries
+};
+Runtime &runtime();
+mgrt_status require_init();
+
+// Argument validation shared by the kernel launchers.
+mgrt_status check_grid(const mgrt_grid *g, const char *who);
+
+constexpr int kMaxPartials = 1 << 16;
+
+} // namespace mgrt
+
+#endif

@@ -1,0 +1,725 @@
+// mgrt_kernels.hip -- gfx950 kernels of the multigrid V-cycle and their C-ABI launchers.
+//
+// Numerics: every expression below keeps the operand order and the mixed precision of the
+// reference's OpenCL source (bare literals such as 1.0/6.0 are double, so the float build does
+// those products in double and rounds once).  The file is compiled with -ffp-contract=off: a
+// fused multiply-add anywhere here would change results in the last bit.
+//
+// Wavefronts are 64 wide; blocks are one or four wavefronts.  All kernels are HBM-bound stencils:
+// no matrix cores.
+#include "mgrt_internal.h"
+
+using namespace mgrt;
+
+namespace {
+
+constexpr int kWave = 64;
+
+// ---- cell classes ---------------------------------------------------------------------------
+// Replaces getCellType/isBorder on a NaN-encoded Cell (mg_1.cl:14-26).  With a byte map the class
+// is one load; for a box it is index arithmetic and costs no memory traffic.
+template <int DIM, bool MAP>
+__device__ __forceinline__ int cell_class(const mgrt_grid &g, int x, int y, int z)
+{
+    if (MAP)
+        return g.cells[x + (long long)g.pitch * y + g.slab * z];
+    const int yg = y + g.y0;
+    if (DIM == 3) {
+        if (yg == 0) return g.face[2];
+        if (yg == g.gny - 1) return g.face[3];
+        if (x == 0) return g.face[0];
+        if (x == g.nx - 1) return g.face[1];
+        if (z == 0) return g.face[4];
+        if (z == g.nz - 1) return g.face[5];
+    } else {
+        if (x == 0) return g.face[0];
+        if (x == g.nx - 1) return g.face[1];
+        if (yg == 0) return g.face[2];
+        if (yg == g.gny - 1) return g.face[3];
+    }
+    return MGRT_CELL_INNER;
+}
+
+__device__ __forceinline__ bool is_border(int t)
+{
+    return t == MGRT_CELL_DIRICHLET || t == MGRT_CELL_NEUMANN;
+}
+
+// ---- smoother, 3D: one colour pass ------------------------------------------------------------
+// iteration_kernel + do_rbgauss + jacobi_iteration, mg_1.cl:29-43,56-104.  One thread owns one
+// (x,y) column of the active colour and marches it in ascending z: u_new[z-1] is carried in a
+// register, u_old[z+1] comes from the prefetch ring.  The four in-plane neighbours have the other
+// colour and are not written by this pass.  PF planes of loads are kept in flight per thread.
+template <class R> struct PlaneVals {
+    R xm, xp, ym, yp, own, f;
+    int t;
+};
+
+template <class R, bool MAP, int PF>
+__global__ __launch_bounds__(kWave) void k_smooth3d_pass(mgrt_grid g, R *u, const R *__restrict__ f,
+                                                         R omega, int odd, int zcount, int ylo, int yhi)
+{
+    const int hx = (g.nx + 1) / 2;
+    const long long idx = (long long)blockIdx.x * kWave + threadIdx.x;
+    if (idx >= (long long)hx * (yhi - ylo))
+        return;
+    const int y = ylo + (int)(idx / hx);
+    const int x = 2 * (int)(idx % hx) + ((odd + y + g.y0) & 1);
+    if (x >= g.nx)
+        return;
+    const long long p = g.pitch, s = g.slab;
+    const long long col = x + p * y;
+    // planes whose `own` value is needed: z < zcount, plus plane zcount as u_old[z+1] of the last
+    const int zload = zcount < g.nz ? zcount + 1 : g.nz;
+
+    auto load_plane = [&](int z) {
+        PlaneVals<R> v;
+        v.t = z < zcount ? cell_class<3, MAP>(g, x, y, z) : MGRT_CELL_OUTER;
+        const long long b = col + s * z;
+        v.own = u[b];
+        v.xm = v.xp = v.ym = v.yp = v.f = 0;
+        if (v.t == MGRT_CELL_INNER) {
+            v.xp = u[b + 1];
+            v.xm = u[b - 1];
+            v.yp = u[b + p];
+            v.ym = u[b - p];
+            v.f = f[b];
+        } else if (v.t == MGRT_CELL_DIRICHLET) {
+            v.f = f[b];
+        }
+        return v;
+    };
+
+    PlaneVals<R> ring[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+        if (k < zload)
+            ring[k] = load_plane(k);
+
+    R below = 0; // value of plane z-1 as this pass leaves it
+    for (int z0 = 0; z0 < zcount; z0 += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int z = z0 + k;
+            if (z < zcount) {
+                const PlaneVals<R> c = ring[k];
+                if (z + PF < zload)
+                    ring[k] = load_plane(z + PF);
+                const R above = z + 1 < zload ? ring[(k + 1) % PF].own : (R)0;
+                R next = c.own;
+                if (c.t == MGRT_CELL_INNER) {
+                    const R val = (1.0 / 6.0) * (c.xp + c.xm + c.yp + c.ym + above + below - c.f);
+                    next = val * omega + (1.0 - omega) * c.own;
+                    u[col + s * z] = next;
+                } else if (c.t == MGRT_CELL_DIRICHLET) {
+                    next = c.f;
+                    u[col + s * z] = next;
+                }
+                below = next;
+            }
+        }
+    }
+}
+
+// ---- smoother, 2D: one colour pass (true red-black, mg_0.cl:29-40,52-98) ----------------------
+template <class R, bool MAP>
+__global__ __launch_bounds__(256) void k_smooth2d_pass(mgrt_grid g, R *u, const R *__restrict__ f, R omega,
+                                                       int odd, int ylo, int yhi)
+{
+    const int hx = (g.nx + 1) / 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)hx * (yhi - ylo))
+        return;
+    const int y = ylo + (int)(idx / hx);
+    const int x = 2 * (int)(idx % hx) + ((odd + y + g.y0) & 1);
+    if (x >= g.nx)
+        return;
+    const long long p = g.pitch, b = x + p * y;
+    const int t = cell_class<2, MAP>(g, x, y, 0);
+    if (t == MGRT_CELL_INNER) {
+        const R val = 0.25 * (u[b + 1] + u[b - 1] + u[b + p] + u[b - p] - f[b]);
+        u[b] = val * omega + (1.0 - omega) * u[b];
+    } else if (t == MGRT_CELL_DIRICHLET) {
+        u[b] = f[b];
+    }
+}
+
+// ---- block reduction of doubles into one partial per block (fixed order: deterministic) -------
+template <bool MAX> __device__ __forceinline__ double combine(double a, double b)
+{
+    return MAX ? (a < b ? b : a) : a + b;
+}
+
+template <bool MAX> __device__ __forceinline__ double wave_reduce(double v)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1)
+        v = combine<MAX>(v, __shfl_down(v, off, kWave));
+    return v;
+}
+
+template <bool MAX, int NWAVES> __device__ __forceinline__ void block_reduce_store(double v, double *partial)
+{
+    __shared__ double sh[NWAVES];
+    v = wave_reduce<MAX>(v);
+    const int lane = threadIdx.x % kWave, w = threadIdx.x / kWave;
+    if (lane == 0)
+        sh[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = sh[0];
+#pragma unroll
+        for (int i = 1; i < NWAVES; ++i)
+            a = combine<MAX>(a, sh[i]);
+        *partial = a;
+    }
+}
+
+// second stage: one block folds the partials in a fixed order
+template <bool MAX> __global__ __launch_bounds__(256) void k_fold_partials(const double *partials, int n, double *out)
+{
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += 256)
+        v = combine<MAX>(v, partials[i]);
+    block_reduce_store<MAX, 4>(v, out);
+}
+
+// ---- residual (mg_1.cl:46-53,111-133, mg_0.cl:43-49,105-126) -----------------------------------
+// One thread per (x,y), marching a chunk of ZC planes with the three z values of its column held
+// in registers.  NORM adds sum(r*r) in double, one partial per block.
+template <class R, int DIM, bool MAP, bool NORM, int ZC>
+__global__ __launch_bounds__(256) void k_residual(mgrt_grid g, R *r, const R *__restrict__ u,
+                                                  const R *__restrict__ f, int zero_unwritten,
+                                                  double *partials, int ylo, int yhi)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx < (long long)g.nx * (yhi - ylo);
+    double acc = 0;
+    if (live) {
+        const int y = ylo + (int)(idx / g.nx), x = (int)(idx % g.nx);
+        const long long p = g.pitch, s = g.slab;
+        const int zb = DIM == 3 ? blockIdx.y * ZC : 0;
+        const int ze = DIM == 3 ? (zb + ZC < g.nz ? zb + ZC : g.nz) : 1;
+        long long b = x + p * y + s * zb;
+        R um = (DIM == 3 && zb > 0) ? u[b - s] : (R)0;
+        R uc = u[b];
+        for (int z = zb; z < ze; ++z, b += s) {
+            const R up = (DIM == 3 && z + 1 < g.nz) ? u[b + s] : (R)0;
+            const int t = cell_class<DIM, MAP>(g, x, y, z);
+            if (t == MGRT_CELL_INNER) {
+                R v;
+                if (DIM == 3)
+                    v = f[b] - (u[b + 1] + u[b - 1] + u[b + p] + u[b - p] + up + um - 6 * uc);
+                else
+                    v = f[b] - (u[b + 1] + u[b - 1] + u[b + p] + u[b - p] - 4 * uc);
+                r[b] = v;
+                if (NORM)
+                    acc += (double)v * (double)v;
+            } else if (t == MGRT_CELL_DIRICHLET) {
+                const R v = f[b] - uc;
+                r[b] = v;
+                if (NORM)
+                    acc += (double)v * (double)v;
+            } else if (zero_unwritten) {
+                r[b] = 0;
+            }
+            um = uc;
+            uc = up;
+        }
+    }
+    if (NORM)
+        block_reduce_store<false, 4>(acc, partials + blockIdx.x + (size_t)gridDim.x * blockIdx.y);
+}
+
+// ---- full-weighting restriction (mg_1.cl:146-190, mg_0.cl:139-157) ----------------------------
+// One thread per coarse point.  `fine`/`coarse` may be y-slabs: coarse global row jg maps to fine
+// global row 2*jg.
+template <class R, int DIM, bool MAP>
+__global__ __launch_bounds__(256) void k_restrict(mgrt_grid fg, mgrt_grid cg, R *rc, const R *__restrict__ rf,
+                                                  int cylo, int cyhi)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)cg.nx * (cyhi - cylo))
+        return;
+    const int j = cylo + (int)(idx / cg.nx), i = (int)(idx % cg.nx);
+    const int k = DIM == 3 ? blockIdx.y : 0;
+    const int x = 2 * i, y = 2 * (j + cg.y0) - fg.y0, z = 2 * k;
+    const long long p = fg.pitch, s = fg.slab;
+    const R *c = rf + x + p * y + s * z;
+    const long long d = i + (long long)cg.pitch * j + cg.slab * k;
+
+    // forward 2x2(x2) block, tested in the reference's short-circuit order; cells past the far
+    // faces are never classified because the first test already hits the face
+    bool border = is_border(cell_class<DIM, MAP>(fg, x, y, z));
+    if (!border) {
+        border = is_border(cell_class<DIM, MAP>(fg, x + 1, y, z)) ||
+                 is_border(cell_class<DIM, MAP>(fg, x, y + 1, z)) ||
+                 is_border(cell_class<DIM, MAP>(fg, x + 1, y + 1, z));
+        if (DIM == 3 && !border)
+            border = is_border(cell_class<DIM, MAP>(fg, x, y, z + 1)) ||
+                     is_border(cell_class<DIM, MAP>(fg, x + 1, y, z + 1)) ||
+                     is_border(cell_class<DIM, MAP>(fg, x, y + 1, z + 1)) ||
+                     is_border(cell_class<DIM, MAP>(fg, x + 1, y + 1, z + 1));
+    }
+    if (border) {
+        rc[d] = c[0];
+    } else if (DIM == 3) {
+        rc[d] = 1.0 / 64.0 * (c[s + p + 1] + c[s + p - 1] + c[s - p + 1] + c[s - p - 1] + c[-s + p + 1] +
+                              c[-s + p - 1] + c[-s - p + 1] + c[-s - p - 1]) +
+                1.0 / 32.0 * (c[p + 1] + c[p - 1] + c[-p + 1] + c[-p - 1] + c[-s + p] + c[-s - p] + c[-s + 1] +
+                              c[-s - 1] + c[s + p] + c[s - p] + c[s + 1] + c[s - 1]) +
+                1.0 / 16.0 * (c[p] + c[-p] + c[1] + c[-1] + c[s] + c[-s]) + 1.0 / 8.0 * (c[0]);
+    } else {
+        rc[d] = 1.0 / 16.0 * (c[-p - 1] + c[-p + 1] + c[p - 1] + c[p + 1]) +
+                1.0 / 8.0 * (c[-p] + c[1] + c[-1] + c[p]) + 1.0 / 4.0 * (c[0]);
+    }
+}
+
+// ---- interpolation (mg_1.cl:200-267, mg_0.cl:167-222) -----------------------------------------
+// dot(real4, real4) evaluated left to right in R: ((a0*b0 + a1*b1) + a2*b2) + a3*b3.
+template <class R> __device__ __forceinline__ R dot4(R a0, R a1, R a2, R a3, R b0, R b1, R b2, R b3)
+{
+    return a0 * b0 + a1 * b1 + a2 * b2 + a3 * b3;
+}
+
+// MODE 0: out = u + 4*P(e) (residual_correct_kernel); MODE 1: out = P(e) (prolongation_kernel).
+// The weight of a coarse neighbour one step up in x/y/z is 0 when the fine index is even; such
+// neighbours are still multiplied in, as the reference does, but their index is clamped to the
+// coarse array so that no address outside it is formed.
+template <class R, int DIM, bool MAP, int MODE>
+__global__ __launch_bounds__(256) void k_interp(mgrt_grid fg, mgrt_grid cg, R *out, const R *u,
+                                                const R *__restrict__ e, int ylo, int yhi)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)fg.nx * (yhi - ylo))
+        return;
+    const int y = ylo + (int)(idx / fg.nx), x = (int)(idx % fg.nx);
+    const int z = DIM == 3 ? blockIdx.y : 0;
+    const int yg = y + fg.y0;
+    const long long d = x + (long long)fg.pitch * y + fg.slab * z;
+    const int ci = x / 2, cj = yg / 2 - cg.y0, ck = z / 2;
+    const int ci1 = ci + 1 < cg.nx ? ci + 1 : ci;
+    const int cj1 = cj + 1 < cg.ny ? cj + 1 : cj;
+    const long long cp = cg.pitch, cs = cg.slab;
+    const R *e0 = e + cs * ck;
+    R val;
+    if (is_border(cell_class<DIM, MAP>(fg, x, y, z))) {
+        val = e0[ci + cp * cj];
+    } else if (DIM == 2 && MODE == 1) {
+        // the 2D prolongation kernel spells the four parity cases out (mg_0.cl:210-218)
+        if (x % 2 == 0 && yg % 2 == 0)
+            val = e0[ci + cp * cj];
+        else if (x % 2 == 0)
+            val = 0.5 * (e0[ci + cp * cj] + e0[ci + cp * cj1]);
+        else if (yg % 2 == 0)
+            val = 0.5 * (e0[ci + cp * cj] + e0[ci1 + cp * cj]);
+        else
+            val = 0.25 * (e0[ci + cp * cj] + e0[ci + cp * cj1] + e0[ci1 + cp * cj1] + e0[ci1 + cp * cj]);
+    } else {
+        const R wu = 0.5 * (x % 2), ww = 0.5 * (yg % 2);
+        if (DIM == 3) {
+            const R wv = 0.5 * (z % 2);
+            const int ck1 = ck + 1 < cg.nz ? ck + 1 : ck;
+            const R *e1 = e + cs * ck1;
+            const R n10 = (1.0 - wu) * (1.0 - ww) * (1.0 - wv), n11 = (1.0 - ww) * wu * (1.0 - wv),
+                    n12 = (1.0 - wu) * ww * (1.0 - wv), n13 = ww * wu * (1.0 - wv);
+            const R n20 = (1.0 - wu) * (1.0 - ww) * wv, n21 = (1.0 - ww) * wu * wv, n22 = (1.0 - wu) * ww * wv,
+                    n23 = ww * wu * wv;
+            val = dot4<R>(e0[ci + cp * cj], e0[ci1 + cp * cj], e0[ci + cp * cj1], e0[ci1 + cp * cj1], n10, n11, n12,
+                          n13) +
+                  dot4<R>(e1[ci + cp * cj], e1[ci1 + cp * cj], e1[ci + cp * cj1], e1[ci1 + cp * cj1], n20, n21, n22,
+                          n23);
+        } else {
+            const R n0 = (1.0 - wu) * (1.0 - ww), n1 = (1.0 - ww) * wu, n2 = (1.0 - wu) * ww, n3 = ww * wu;
+            val = dot4<R>(e0[ci + cp * cj], e0[ci1 + cp * cj], e0[ci + cp * cj1], e0[ci1 + cp * cj1], n0, n1, n2, n3);
+        }
+    }
+    out[d] = MODE == 0 ? u[d] + val * 4 : val;
+}
+
+// ---- element-wise helpers -----------------------------------------------------------------------
+template <class R, int DIM, bool MAP> __global__ __launch_bounds__(256) void k_zero_outside(mgrt_grid g, R *u)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)g.nx * g.ny)
+        return;
+    const int y = (int)(idx / g.nx), x = (int)(idx % g.nx), z = DIM == 3 ? blockIdx.y : 0;
+    if (cell_class<DIM, MAP>(g, x, y, z) == MGRT_CELL_OUTER)
+        u[x + (long long)g.pitch * y + g.slab * z] = 0;
+}
+
+template <class R> __global__ __launch_bounds__(256) void k_diff(mgrt_grid g, R *out, const R *a, const R *b)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)g.nx * g.ny)
+        return;
+    const int y = (int)(idx / g.nx), x = (int)(idx % g.nx);
+    const long long i = x + (long long)g.pitch * y + g.slab * blockIdx.y;
+    out[i] = a[i] - b[i];
+}
+
+// exact sum of squares / max |x|, double accumulation, one partial per block
+template <class R, bool MAX>
+__global__ __launch_bounds__(256) void k_norm_partials(mgrt_grid g, const R *__restrict__ x, double *partials,
+                                                       int ylo, int yhi, int zc)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    double acc = 0;
+    if (idx < (long long)g.nx * (yhi - ylo)) {
+        const int y = ylo + (int)(idx / g.nx), xx = (int)(idx % g.nx);
+        const int zb = blockIdx.y * zc, ze = zb + zc < g.nz ? zb + zc : g.nz;
+        long long b = xx + (long long)g.pitch * y + g.slab * zb;
+        for (int z = zb; z < ze; ++z, b += g.slab) {
+            const double v = (double)x[b];
+            acc = MAX ? combine<true>(acc, v < 0 ? -v : v) : acc + v * v;
+        }
+    }
+    block_reduce_store<MAX, 4>(acc, partials + blockIdx.x + (size_t)gridDim.x * blockIdx.y);
+}
+
+// ---- the reference's lossy reduction tree (auxiliary.cpp:119-135, common_kernels.cl:13-53) -----
+// Level sizes go n -> max(1, n/4); output i folds inputs [4i, min(n, 4i+4)) left to right in R
+// starting from 0.  SQUARE applies the element-wise square of the L2Norm kernel on the way in;
+// MAX is the LInfNorm fold max(res, fabs(x)).
+template <class R, bool MAX, bool SQUARE>
+__global__ __launch_bounds__(256) void k_reftree_level(const R *in, R *out, long long n, long long newn)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= newn)
+        return;
+    const long long end = n < 4 * i + 4 ? n : 4 * i + 4;
+    R res = 0.0;
+    for (long long b = 4 * i; b < end; ++b) {
+        R v = in[b];
+        if (SQUARE)
+            v = v * v;
+        if (MAX) {
+            const R a = v < 0 ? -v : v;
+            res = res < a ? a : res;
+        } else {
+            res += v;
+        }
+    }
+    out[i] = res;
+}
+
+inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// ---- launchers ---------------------------------------------------------------------------------
+template <class R>
+mgrt_status smooth_pass(const mgrt_grid *g, R *u, const R *f, R omega, int odd, int zcount, int ylo, int yhi,
+                        mgrt_stream s)
+{
+    if (mgrt_status st = require_init()) return st;
+    if (mgrt_status st = check_grid(g, "mgrt_smooth_pass")) return st;
+    MGRT_REQUIRE(u && f, "mgrt_smooth_pass: null field");
+    MGRT_REQUIRE(odd == 0 || odd == 1, "mgrt_smooth_pass: odd must be 0 or 1");
+    MGRT_REQUIRE(0 <= ylo && ylo <= yhi && yhi <= g->ny, "mgrt_smooth_pass: rows [%d,%d) outside [0,%d)", ylo, yhi,
+                 g->ny);
+    if (g->dim == 2)
+        zcount = 1;
+    MGRT_REQUIRE(zcount >= 0 && zcount <= g->nz, "mgrt_smooth_pass: zcount %d outside [0,%d]", zcount, g->nz);
+    const long long n = (long long)((g->nx + 1) / 2) * (yhi - ylo);
+    if (n == 0 || zcount == 0)
+        return MGRT_OK;
+    hipStream_t hs = (hipStream_t)s;
+    if (g->dim == 3) {
+        constexpr int PF = 8;
+        if (g->cells)
+            k_smooth3d_pass<R, true, PF><<<blocks_for(n, kWave), kWave, 0, hs>>>(*g, u, f, omega, odd, zcount, ylo, yhi);
+        else
+            k_smooth3d_pass<R, false, PF><<<blocks_for(n, kWave), kWave, 0, hs>>>(*g, u, f, omega, odd, zcount, ylo, yhi);
+    } else {
+        if (g->cells)
+            k_smooth2d_pass<R, true><<<blocks_for(n, 256), 256, 0, hs>>>(*g, u, f, omega, odd, ylo, yhi);
+        else
+            k_smooth2d_pass<R, false><<<blocks_for(n, 256), 256, 0, hs>>>(*g, u, f, omega, odd, ylo, yhi);
+    }
+    MGRT_HIP(hipGetLastError());
+    return MGRT_OK;
+}
+
+template <class R>
+mgrt_status smooth(const mgrt_grid *g, R *u, const R *f, R omega, int iters, int zcount, mgrt_stream s)
+{
+    MGRT_REQUIRE(iters >= 0, "mgrt_smooth: iters < 0");
+    MGRT_REQUIRE(g != nullptr, "mgrt_smooth: grid is null");
+    for (int i = 0; i < iters; ++i)
+        for (int odd = 0; odd < 2; ++odd)
+            if (mgrt_status st = smooth_pass<R>(g, u, f, omega, odd, zcount, 0, g->ny, s))
+                return st;
+    return MGRT_OK;
+}
+
+template <bool MAX> mgrt_status fold(int nparts, double *out, hipStream_t hs)
+{
+    k_fold_partials<MAX><<<1, 256, 0, hs>>>(runtime().partials, nparts, out);
+    MGRT_HIP(hipGetLastError());
+    return MGRT_OK;
+}
+
+template <class R>
+mgrt_status residual(const mgrt_grid *g, R *r, const R *u, const R *f, int zero_unwritten, double *norm2, int ylo,
+                     int yhi, mgrt_stream s)
+{
+    if (mgrt_status st = require_init()) return st;
+    if (mgrt_status st = check_grid(g, "mgrt_residual")) return st;
+    MGRT_REQUIRE(r && u && f, "mgrt_residual: null field");
+    MGRT_REQUIRE(r != u && r != f, "mgrt_residual: r must not alias u or f");
+    MGRT_REQUIRE(0 <= ylo && ylo <= yhi && yhi <= g->ny, "mgrt_residual: rows [%d,%d) outside [0,%d)", ylo, yhi, g->ny);
+    hipStream_t hs = (hipStream_t)s;
+    const long long n = (long long)g->nx * (yhi - ylo);
+    if (n == 0) {
+        if (norm2)
+            MGRT_HIP(hipMemsetAsync(norm2, 0, sizeof(double), hs));
+        return MGRT_OK;
+    }
+    constexpr int ZC = 16;
+    dim3 grid(blocks_for(n, 256), g->dim == 3 ? blocks_for(g->nz, ZC) : 1);
+    const int nparts = (int)(grid.x * grid.y);
+    MGRT_REQUIRE(!norm2 || (size_t)nparts <= runtime().partials_cap, "mgrt_residual: grid too large for the fused norm");
+    double *parts = runtime().partials;
+#define MGRT_LAUNCH_RES(DIM, MAP, NORM)                                                                      \
+    k_residual<R, DIM, MAP, NORM, ZC><<<grid, 256, 0, hs>>>(*g, r, u, f, zero_unwritten, parts, ylo, yhi)
+    const bool map = g->cells != nullptr, nrm = norm2 != nullptr;
+    if (g->dim == 3) {
+        if (map) { if (nrm) MGRT_LAUNCH_RES(3, true, true); else MGRT_LAUNCH_RES(3, true, false); }
+        else     { if (nrm) MGRT_LAUNCH_RES(3, false, true); else MGRT_LAUNCH_RES(3, false, false); }
+    } else {
+        if (map) { if (nrm) MGRT_LAUNCH_RES(2, true, true); else MGRT_LAUNCH_RES(2, true, false); }
+        else     { if (nrm) MGRT_LAUNCH_RES(2, false, true); else MGRT_LAUNCH_RES(2, false, false); }
+    }
+#undef MGRT_LAUNCH_RES
+    MGRT_HIP(hipGetLastError());
+    if (nrm)
+        return fold<false>(nparts, norm2, hs);
+    return MGRT_OK;
+}
+
+mgrt_status check_pair(const mgrt_grid *fine, const mgrt_grid *coarse, const char *who)
+{
+    if (mgrt_status st = check_grid(fine, who)) return st;
+    if (mgrt_status st = check_grid(coarse, who)) return st;
+    MGRT_REQUIRE(fine->dim == coarse->dim, "%s: fine and coarse dim differ", who);
+    MGRT_REQUIRE(coarse->nx == (fine->nx + 1) / 2 && coarse->gny == (fine->gny + 1) / 2 &&
+                     coarse->nz == (fine->nz + 1) / 2,
+                 "%s: coarse extents (%d,%d,%d) are not (n+1)/2 of the fine (%d,%d,%d)", who, coarse->nx,
+                 coarse->gny, coarse->nz, fine->nx, fine->gny, fine->nz);
+    return MGRT_OK;
+}
+
+template <class R>
+mgrt_status restrict_fw(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, const R *rf, int cylo, int cyhi,
+                        mgrt_stream s)
+{
+    if (mgrt_status st = require_init()) return st;
+    if (mgrt_status st = check_pair(fine, coarse, "mgrt_restrict")) return st;
+    MGRT_REQUIRE(rc && rf, "mgrt_restrict: null field");
+    MGRT_REQUIRE(0 <= cylo && cylo <= cyhi && cyhi <= coarse->ny, "mgrt_restrict: coarse rows [%d,%d) outside [0,%d)",
+                 cylo, cyhi, coarse->ny);
+    if (cylo < cyhi) {
+        // fine rows 2*jg-1 .. 2*jg+1 must be held (the outermost only where they exist globally)
+        const int flo = 2 * (cylo + coarse->y0) - fine->y0, fhi = 2 * (cyhi - 1 + coarse->y0) - fine->y0;
+        MGRT_REQUIRE(flo >= 0 && fhi < fine->ny, "mgrt_restrict: fine slab does not hold rows %d..%d", flo + fine->y0,
+                     fhi + fine->y0);
+        MGRT_REQUIRE((flo >= 1 || flo + fine->y0 == 0) && (fhi + 1 < fine->ny || fhi + fine->y0 == fine->gny - 1),
+                     "mgrt_restrict: fine slab lacks the halo row of the requested coarse rows");
+    }
+    const long long n = (long long)coarse->nx * (cyhi - cylo);
+    if (n == 0)
+        return MGRT_OK;
+    dim3 grid(blocks_for(n, 256), coarse->nz);
+    hipStream_t hs = (hipStream_t)s;
+    const bool map = fine->cells != nullptr;
+    if (fine->dim == 3) {
+        if (map) k_restrict<R, 3, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi);
+        else     k_restrict<R, 3, false><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi);
+    } else {
+        if (map) k_restrict<R, 2, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi);
+        else     k_restrict<R, 2, false><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi);
+    }
+    MGRT_HIP(hipGetLastError());
+    return MGRT_OK;
+}
+
+template <class R, int MODE>
+mgrt_status interp(const mgrt_grid *fine, const mgrt_grid *coarse, R *out, const R *u, const R *e, int ylo, int yhi,
+                   mgrt_stream s)
+{
+    const char *who = MODE == 0 ? "mgrt_correct" : "mgrt_prolong";
+    if (mgrt_status st = require_init()) return st;
+    if (mgrt_status st = check_pair(fine, coarse, who)) return st;
+    MGRT_REQUIRE(out && e && (MODE == 1 || u), "%s: null field", who);
+    MGRT_REQUIRE(0 <= ylo && ylo <= yhi && yhi <= fine->ny, "%s: rows [%d,%d) outside [0,%d)", who, ylo, yhi, fine->ny);
+    if (ylo < yhi) {
+        const int clo = (ylo + fine->y0) / 2 - coarse->y0, chi = (yhi - 1 + fine->y0 + 1) / 2 - coarse->y0;
+        MGRT_REQUIRE(clo >= 0 && chi < coarse->ny, "%s: coarse slab does not hold rows %d..%d", who, clo + coarse->y0,
+                     chi + coarse->y0);
+    }
+    const long long n = (long long)fine->nx * (yhi - ylo);
+    if (n == 0)
+        return MGRT_OK;
+    dim3 grid(blocks_for(n, 256), fine->nz);
+    hipStream_t hs = (hipStream_t)s;
+    const bool map = fine->cells != nullptr;
+    if (fine->dim == 3) {
+        if (map) k_interp<R, 3, true, MODE><<<grid, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi);
+        else     k_interp<R, 3, false, MODE><<<grid, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi);
+    } else {
+        if (map) k_interp<R, 2, true, MODE><<<grid, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi);
+        else     k_interp<R, 2, false, MODE><<<grid, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi);
+    }
+    MGRT_HIP(hipGetLastError());
+    return MGRT_OK;
+}
+
+template <class R> mgrt_status zero_outside(const mgrt_grid *g, R *u, mgrt_stream s)
+{
+    if (mgrt_status st = require_init()) return st;
+    if (mgrt_status st = check_grid(g, "mgrt_zero_outside")) return st;
+    MGRT_REQUIRE(u, "mgrt_zero_outside: null field");
+    bool any_outer = g->cells != nullptr;
+    for (int i = 0; i < 6 && !any_outer; ++i)
+        any_outer = g->face[i] == MGRT_CELL_OUTER;
+    if (!any_outer)
+        return MGRT_OK; // a box without outer faces has nothing to clear
+    dim3 grid(blocks_for((long long)g->nx * g->ny, 256), g->nz);
+    hipStream_t hs = (hipStream_t)s;
+    if (g->dim == 3) {
+        if (g->cells) k_zero_outside<R, 3, true><<<grid, 256, 0, hs>>>(*g, u);
+        else          k_zero_outside<R, 3, false><<<grid, 256, 0, hs>>>(*g, u);
+    } else {
+        if (g->cells) k_zero_outside<R, 2, true><<<grid, 256, 0, hs>>>(*g, u);
+        else          k_zero_outside<R, 2, false><<<grid, 256, 0, hs>>>(*g, u);
+    }
+    MGRT_HIP(hipGetLastError());
+    return MGRT_OK;
+}
+
+template <class R> mgrt_status diff(const mgrt_grid *g, R *out, const R *a, const R *b, mgrt_stream s)
+{
+    if (mgrt_status st = require_init()) return st;
+    if (mgrt_status st = check_grid(g, "mgrt_diff")) return st;
+    MGRT_REQUIRE(out && a && b, "mgrt_diff: null field");
+    dim3 grid(blocks_for((long long)g->nx * g->ny, 256), g->nz);
+    k_diff<R><<<grid, 256, 0, (hipStream_t)s>>>(*g, out, a, b);
+    MGRT_HIP(hipGetLastError());
+    return MGRT_OK;
+}
+
+template <class R, bool MAX>
+mgrt_status norm(const mgrt_grid *g, const R *x, double *out, int ylo, int yhi, mgrt_stream s)
+{
+    const char *who = MAX ? "mgrt_maxabs" : "mgrt_sumsq";
+    if (mgrt_status st = require_init()) return st;
+    if (mgrt_status st = check_grid(g, who)) return st;
+    MGRT_REQUIRE(x && out, "%s: null pointer", who);
+    MGRT_REQUIRE(0 <= ylo && ylo <= yhi && yhi <= g->ny, "%s: rows [%d,%d) outside [0,%d)", who, ylo, yhi, g->ny);
+    hipStream_t hs = (hipStream_t)s;
+    const long long n = (long long)g->nx * (yhi - ylo);
+    if (n == 0) {
+        MGRT_HIP(hipMemsetAsync(out, 0, sizeof(double), hs));
+        return MGRT_OK;
+    }
+    const unsigned gx = blocks_for(n, 256);
+    // keep the number of partials bounded: deepen the z chunk as needed
+    int zc = 16;
+    while ((long long)gx * blocks_for(g->nz, zc) > (long long)runtime().partials_cap)
+        zc *= 2;
+    dim3 grid(gx, blocks_for(g->nz, zc));
+    MGRT_REQUIRE((size_t)grid.x * grid.y <= runtime().partials_cap, "%s: grid too large", who);
+    k_norm_partials<R, MAX><<<grid, 256, 0, hs>>>(*g, x, runtime().partials, ylo, yhi, zc);
+    MGRT_HIP(hipGetLastError());
+    return fold<MAX>((int)(grid.x * grid.y), out, hs);
+}
+
+// Blocking: allocates the tree's intermediate arrays like the reference does (auxiliary.cpp:124).
+template <class R, bool MAX> mgrt_status reftree(const R *x, long long n, R *result, mgrt_stream s)
+{
+    const char *who = MAX ? "mgrt_linfnorm_reftree" : "mgrt_l2norm_reftree";
+    if (mgrt_status st = require_init()) return st;
+    MGRT_REQUIRE(x && result && n > 0, "%s: bad argument", who);
+    hipStream_t hs = (hipStream_t)s;
+    R host = 0;
+    if (n == 1) {
+        // performReduction returns its input untouched when size == 1 (auxiliary.cpp:121); the L2
+        // path has squared it first
+        MGRT_HIP(hipMemcpyAsync(&host, x, sizeof(R), hipMemcpyDeviceToHost, hs));
+        MGRT_HIP(hipStreamSynchronize(hs));
+        *result = MAX ? host : (R)sqrt((double)(host * host));
+        return MGRT_OK;
+    }
+    R *buf[2] = {nullptr, nullptr};
+    const long long n1 = n / 4 > 1 ? n / 4 : 1;
+    MGRT_HIP(hipMalloc((void **)&buf[0], sizeof(R) * (size_t)n1));
+    if (hipMalloc((void **)&buf[1], sizeof(R) * (size_t)(n1 / 4 > 1 ? n1 / 4 : 1)) != hipSuccess) {
+        (void)hipFree(buf[0]);
+        return fail((mgrt_status)hipErrorOutOfMemory, "%s: out of device memory", who);
+    }
+    const R *in = x;
+    long long size = n;
+    int which = 0;
+    bool first = true;
+    while (size != 1) {
+        const long long newn = size / 4 > 1 ? size / 4 : 1;
+        if (first && !MAX)
+            k_reftree_level<R, false, true><<<blocks_for(newn, 256), 256, 0, hs>>>(in, buf[which], size, newn);
+        else
+            k_reftree_level<R, MAX, false><<<blocks_for(newn, 256), 256, 0, hs>>>(in, buf[which], size, newn);
+        first = false;
+        in = buf[which];
+        which ^= 1;
+        size = newn;
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(&host, in, sizeof(R), hipMemcpyDeviceToHost, hs);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(hs);
+    (void)hipFree(buf[0]);
+    (void)hipFree(buf[1]);
+    if (e != hipSuccess)
+        return fail((mgrt_status)e, "%s: %s", who, hipGetErrorString(e));
+    *result = MAX ? host : (R)sqrt((double)host);
+    return MGRT_OK;
+}
+
+} // namespace
+
+// ---- C ABI ---------------------------------------------------------------------------------------
+#define MGRT_DEFINE_KERNELS(R, S)                                                                              \
+    extern "C" mgrt_status mgrt_smooth_pass##S(const mgrt_grid *g, R *u, const R *f, R omega, int odd, int zcount, \
+                                               int ylo, int yhi, mgrt_stream s)                                \
+    { return smooth_pass<R>(g, u, f, omega, odd, zcount, ylo, yhi, s); }                                       \
+    extern "C" mgrt_status mgrt_smooth##S(const mgrt_grid *g, R *u, const R *f, R omega, int iters, int zcount, \
+                                          mgrt_stream s)                                                       \
+    { return smooth<R>(g, u, f, omega, iters, zcount, s); }                                                    \
+    extern "C" mgrt_status mgrt_residual##S(const mgrt_grid *g, R *r, const R *u, const R *f, int zero_unwritten, \
+                                            double *norm2, int ylo, int yhi, mgrt_stream s)                    \
+    { return residual<R>(g, r, u, f, zero_unwritten, norm2, ylo, yhi, s); }                                    \
+    extern "C" mgrt_status mgrt_restrict##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, const R *rf, \
+                                            int cylo, int cyhi, mgrt_stream s)                                 \
+    { return restrict_fw<R>(fine, coarse, rc, rf, cylo, cyhi, s); }                                            \
+    extern "C" mgrt_status mgrt_correct##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *out, const R *u,  \
+                                           const R *e, int ylo, int yhi, mgrt_stream s)                        \
+    { return interp<R, 0>(fine, coarse, out, u, e, ylo, yhi, s); }                                             \
+    extern "C" mgrt_status mgrt_prolong##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *out, const R *c,  \
+                                           int ylo, int yhi, mgrt_stream s)                                    \
+    { return interp<R, 1>(fine, coarse, out, nullptr, c, ylo, yhi, s); }                                       \
+    extern "C" mgrt_status mgrt_zero_outside##S(const mgrt_grid *g, R *u, mgrt_stream s)                       \
+    { return zero_outside<R>(g, u, s); }                                                                       \
+    extern "C" mgrt_status mgrt_diff##S(const mgrt_grid *g, R *out, const R *a, const R *b, mgrt_stream s)     \
+    { return diff<R>(g, out, a, b, s); }                                                                       \
+    extern "C" mgrt_status mgrt_sumsq##S(const mgrt_grid *g, const R *x, double *out, int ylo, int yhi,        \
+                                         mgrt_stream s)                                                        \
+    { return norm<R, false>(g, x, out, ylo, yhi, s); }                                                         \
+    extern "C" mgrt_status mgrt_maxabs##S(const mgrt_grid *g, const R *x, double *out, int ylo, int yhi,       \
+                                          mgrt_stream s)                                                       \
+    { return norm<R, true>(g, x, out, ylo, yhi, s); }                                                          \
+    extern "C" mgrt_status mgrt_l2norm_reftree##S(const R *x, long long n, R *result, mgrt_stream s)           \
+    { return reftree<R, false>(x, n, result, s); }                                                             \
+    extern "C" mgrt_status mgrt_linfnorm_reftree##S(const R *x, long long n, R *result, mgrt_stream s)         \
+    { return reftree<R, true>(x, n, result, s); }
+
+MGRT_DEFINE_KERNELS(float, _f32)
+MGRT_DEFINE_KERNELS(double, _f64)
