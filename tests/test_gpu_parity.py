@@ -175,7 +175,7 @@ def test_cycles_match_golden(dev, path):
     assert np.abs(u.astype(np.float64) - ref_u).max() <= tol * np.abs(ref_u).max()
     assert bits_equal(u, ref_u)
     # exact norm: the summation order differs from the oracle's serial loop, not the values summed
-    assert np.allclose(hist, ref_h, rtol=1e-13, atol=0)
+    assert np.allclose(hist, ref_h, rtol=1e-11, atol=0)
     assert tree[0] == g["l2res_tree"] and tree[1] == g["linfres_tree"]
 
 
