@@ -104,6 +104,12 @@ mgrt_status mgrt_box_cells_host(int dim, int nx, int ny, int nz, const int face[
        calls of mgrt_smooth_pass; free to fuse them.  Replaces the loop of smoother_iterate. */   \
     mgrt_status mgrt_smooth##S(const mgrt_grid *g, R *u, const R *f, R omega, int iters,           \
                                int zcount, mgrt_stream s);                                         \
+    /* One fused z-march: out = S^iters(in) for iters in {1,2}, every field element read once and  \
+       written once; same results as 2*iters calls of mgrt_smooth_pass on a copy of `in`.  3D      \
+       analytic-box grids only (MGRT_E_UNSUPPORTED otherwise: use the pass kernel).  out must not  \
+       alias in.  Replaces the launch loop of smoother_iterate (multigridsolver3D.cpp:124-131). */ \
+    mgrt_status mgrt_smooth_sweep##S(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, \
+                                     int iters, int zcount, mgrt_stream s);                        \
     /* r = f - A u on inner cells, f - u on Dirichlet cells; outer and Neumann cells of r are     \
        left untouched, or set to 0 when zero_unwritten != 0.  Replaces residual_kernel            \
        (mg_1.cl:111-133, mg_0.cl:105-126).  norm2 (device, may be NULL) receives sum(r*r) over    \
@@ -161,6 +167,7 @@ typedef struct mgrt_plan_desc {
     int face[6];      /* box face types, used for every level without an uploaded cell map */
     int zfull;        /* 0: reference z range ceil(nz/2) in the 3D smoother; 1: all planes */
     int use_graph;    /* replay each distinct cycle from a captured hipGraph */
+    int no_fuse;      /* 1: smooth with one launch per colour pass (the unfused schedule) */
 } mgrt_plan_desc;
 
 mgrt_status mgrt_plan_create(mgrt_plan **plan, const mgrt_plan_desc *desc, mgrt_stream s);

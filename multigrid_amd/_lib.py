@@ -35,11 +35,12 @@ class PlanDesc(C.Structure):
     _fields_ = [
         ("dim", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
         ("elem_size", C.c_int), ("face", C.c_int * 6), ("zfull", C.c_int), ("use_graph", C.c_int),
+        ("no_fuse", C.c_int),
     ]
 
 
 # every symbol include/mgrt.h declares; checked by the CPU test-suite against the header
-_KERNELS = ["smooth_pass", "smooth", "residual", "restrict", "correct", "prolong", "zero_outside",
+_KERNELS = ["smooth_pass", "smooth", "smooth_sweep", "residual", "restrict", "correct", "prolong", "zero_outside",
             "diff", "sumsq", "maxabs", "l2norm_reftree", "linfnorm_reftree"]
 _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "upload", "download",
             "stream_create", "stream_destroy", "sync", "zero", "box_cells_host",
@@ -85,6 +86,7 @@ def load():
         ksig = {
             "smooth_pass": [G, p, p, r, i, i, i, i, p],
             "smooth": [G, p, p, r, i, i, p],
+            "smooth_sweep": [G, p, p, p, r, i, i, p],
             "residual": [G, p, p, p, i, p, i, i, p],
             "restrict": [G, G, p, p, i, i, p],
             "correct": [G, G, p, p, p, i, i, p],
@@ -171,6 +173,11 @@ def smooth(g, u, f, omega, iters, zcount=None, stream=None):
                            _stream(stream)))
 
 
+def smooth_sweep(g, out, inp, f, omega, iters, zcount=None, stream=None):
+    check(_fn("smooth_sweep", inp)(C.byref(g), _p(out), _p(inp), _p(f), omega, iters,
+                                   g.nz if zcount is None else zcount, _stream(stream)))
+
+
 def residual(g, r, u, f, zero_unwritten=False, norm2=None, ylo=0, yhi=None, stream=None):
     check(_fn("residual", u)(C.byref(g), _p(r), _p(u), _p(f), int(zero_unwritten), _p(norm2), ylo,
                              g.ny if yhi is None else yhi, _stream(stream)))
@@ -233,7 +240,7 @@ def box_cells_host(shape, faces=ALL_DIRICHLET):
 class Plan:
     """mgrt_plan: pre-allocated hierarchy; iterate/mg/fmg of MultigridSolver{2,3}D on device arrays."""
 
-    def __init__(self, shape, dtype, faces=ALL_DIRICHLET, zfull=False, use_graph=False, stream=None):
+    def __init__(self, shape, dtype, faces=ALL_DIRICHLET, zfull=False, use_graph=False, no_fuse=False, stream=None):
         import torch
         d = PlanDesc()
         if len(shape) == 3:
@@ -244,6 +251,7 @@ class Plan:
         d.face = (C.c_int * 6)(*faces)
         d.zfull = int(zfull)
         d.use_graph = int(use_graph)
+        d.no_fuse = int(no_fuse)
         self.shape, self.dtype = tuple(shape), dtype
         self._h = C.c_void_p()
         check(load().mgrt_plan_create(C.byref(self._h), C.byref(d), _stream(stream)))

@@ -15,6 +15,7 @@ struct mgrt_plan {
     struct Level {
         mgrt_grid g;
         void *r = nullptr;       // residual on this level (fine side of the restriction)
+        void *work = nullptr;    // ping-pong partner of the unknown for the fused smoother sweeps
         void *rhs = nullptr;     // right-hand side of this level (level 0: the caller's f)
         void *e = nullptr;       // unknown of this level (level 0: the caller's u)
         void *fmg_f = nullptr;   // FMG: restricted right-hand side, allocated on first use
@@ -60,6 +61,7 @@ void drop_graph(mgrt_plan *p)
 template <class R> struct K;
 template <> struct K<float> {
     static constexpr auto smooth = mgrt_smooth_f32;
+    static constexpr auto sweep = mgrt_smooth_sweep_f32;
     static constexpr auto residual = mgrt_residual_f32;
     static constexpr auto restrict_ = mgrt_restrict_f32;
     static constexpr auto correct = mgrt_correct_f32;
@@ -67,19 +69,59 @@ template <> struct K<float> {
 };
 template <> struct K<double> {
     static constexpr auto smooth = mgrt_smooth_f64;
+    static constexpr auto sweep = mgrt_smooth_sweep_f64;
     static constexpr auto residual = mgrt_residual_f64;
     static constexpr auto restrict_ = mgrt_restrict_f64;
     static constexpr auto correct = mgrt_correct_f64;
     static constexpr auto prolong = mgrt_prolong_f64;
 };
 
-// iterate(), multigridsolver3D.cpp:41-80, on level l with unknown u and right-hand side f
+// The fused sweep kernel covers 3D analytic-box levels; everything else smooths in place with
+// the single-colour kernel.
+bool sweepable(const mgrt_plan *p, const mgrt_grid &g) { return !p->desc.no_fuse && g.dim == 3 && g.cells == nullptr; }
+
+// `a` smoothing iterations on *cur, as `nsweeps` out-of-place fused sweeps that ping-pong between
+// *cur and *alt (nsweeps between ceil(a/2) and a), or in place when nsweeps == 0.
+template <class R>
+mgrt_status smooth_steps(mgrt_plan *p, mgrt_plan::Level &L, R *&cur, R *&alt, const R *f, R omega, int a, int nsweeps)
+{
+    mgrt_stream s = (mgrt_stream)p->stream;
+    const int zc = zcount_of(p, L.g);
+    if (nsweeps == 0)
+        return K<R>::smooth(&L.g, cur, f, omega, a, zc, s);
+    for (int i = 0; i < nsweeps; ++i) {
+        // spread the iterations: the first (a - nsweeps) sweeps do two, the rest one
+        const int n = i < a - nsweeps ? 2 : 1;
+        if (mgrt_status st = K<R>::sweep(&L.g, alt, cur, f, omega, n, zc, s))
+            return st;
+        R *t = cur;
+        cur = alt;
+        alt = t;
+    }
+    return MGRT_OK;
+}
+
+// iterate(), multigridsolver3D.cpp:41-80, on level l with unknown u and right-hand side f.
+// The result is left in u.
 template <class R> mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int a2, int v)
 {
     mgrt_plan::Level &L = p->lv[l];
     mgrt_stream s = (mgrt_stream)p->stream;
-    if (mgrt_status st = K<R>::smooth(&L.g, u, f, omega, a1, zcount_of(p, L.g), s))
-        return st;
+    R *cur = u, *alt = (R *)L.work;
+    // Number of out-of-place sweeps for the pre- and post-smoother: as few as possible, but an
+    // even total so that the result lands in u without a copy.
+    int n1 = 0, n2 = 0;
+    if (sweepable(p, L.g)) {
+        n1 = (a1 + 1) / 2;
+        n2 = (a2 + 1) / 2;
+        if ((n1 + n2) % 2) {
+            if (n2 < a2) ++n2;
+            else if (n1 < a1) ++n1;
+        }
+    }
+    if (a1 > 0)
+        if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a1, n1))
+            return st;
     if (recurses(L.g)) {
         mgrt_plan::Level &C = p->lv[l + 1];
         for (int k = 0; k < v; ++k) {
@@ -87,18 +129,23 @@ template <class R> mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R 
                 return st;
             // outer/Neumann cells of the residual are defined as 0 (the reference reads
             // uninitialised memory there)
-            if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, u, f, 1, nullptr, 0, L.g.ny, s))
+            if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, 0, L.g.ny, s))
                 return st;
             if (mgrt_status st = K<R>::restrict_(&L.g, &C.g, (R *)C.rhs, (const R *)L.r, 0, C.g.ny, s))
                 return st;
             if (mgrt_status st = iterate<R>(p, l + 1, (R *)C.e, (const R *)C.rhs, omega, a1, a2, v))
                 return st;
             // in place: same values as the out-of-place kernel followed by the handle swap (:70-72)
-            if (mgrt_status st = K<R>::correct(&L.g, &C.g, u, u, (const R *)C.e, 0, L.g.ny, s))
+            if (mgrt_status st = K<R>::correct(&L.g, &C.g, cur, cur, (const R *)C.e, 0, L.g.ny, s))
                 return st;
         }
     }
-    return K<R>::smooth(&L.g, u, f, omega, a2, zcount_of(p, L.g), s);
+    if (a2 > 0)
+        if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a2, n2))
+            return st;
+    if (cur != u) // odd number of sweeps (only when a1 + a2 == 1): bring the result home
+        MGRT_HIP(hipMemcpyAsync(u, cur, L.n * sizeof(R), hipMemcpyDeviceToDevice, p->stream));
+    return MGRT_OK;
 }
 
 template <class R> mgrt_status run_cycle(mgrt_plan *p, R *u, const R *f, R omega, int a1, int a2, int v)
@@ -251,6 +298,8 @@ mgrt_status mgrt_plan_create(mgrt_plan **plan, const mgrt_plan_desc *d, mgrt_str
         hipError_t e = hipSuccess;
         if (l + 1 < p->lv.size())
             e = hipMalloc(&L.r, L.n * w);
+        if (e == hipSuccess && d->dim == 3 && !d->no_fuse)
+            e = hipMalloc(&L.work, L.n * w);
         if (e == hipSuccess && l > 0)
             e = hipMalloc(&L.rhs, L.n * w);
         if (e == hipSuccess && l > 0)
@@ -272,6 +321,7 @@ mgrt_status mgrt_plan_destroy(mgrt_plan *p)
     drop_graph(p);
     for (auto &L : p->lv) {
         (void)hipFree(L.r);
+        (void)hipFree(L.work);
         (void)hipFree(L.rhs);
         (void)hipFree(L.e);
         (void)hipFree(L.fmg_f);

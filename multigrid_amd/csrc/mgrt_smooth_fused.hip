@@ -1,0 +1,454 @@
+// mgrt_smooth_fused.hip -- the 3D smoother as one z-march that performs whole red-black
+// iterations per sweep: `out = S^iters(in)` with every element of `in` and `f` read once and every
+// element of `out` written once (plus tile halos, which are L2 hits).
+//
+// Why this is legal.  The reference's 3D colouring ignores z (mg_1.cl:98), so inside one colour
+// pass each (x,y) column is a recurrence in ascending z, and the four in-plane neighbours of a
+// point always have the other colour.  Hence at plane z the first colour needs only the other
+// colour's previous values of plane z, its own new value at z-1 and its own old value at z+1; the
+// second colour needs the first colour's new values of plane z.  Both passes of an iteration can
+// therefore be applied plane by plane in one march, and iteration k+1 can follow iteration k two
+// planes behind.  Every point is still computed by exactly the reference's expression from exactly
+// the values the serial NDRange schedule would feed it, so the result is identical bit for bit to
+// 2*iters launches of the single-colour kernel.
+//
+// Shape.  A block of NW wavefronts owns a tile of 64 x (NW*SR) columns including a halo of
+// H = 2*iters columns on every side (each colour update consumes one ring of halo).  A wavefront
+// owns a strip of SR consecutive rows, one lane per x; a lane keeps its SR columns in registers
+// for all planes in flight:
+//   C[c][d][j]  value of the colour-c point of row pair j (rows 2j, 2j+1) at ring depth d, where
+//               depth d is plane (t+1)-d at time step t: d=0 is the raw plane just loaded,
+//               d=2k-1 the plane iteration k updates, d=2k the plane below it (its z-1 carry),
+//               d=2*iters the plane that has just been finished and stored;
+//   F[c][d][j]  the right-hand side of the same points, d < 2*iters;
+//   prefetch registers for PF further planes of `in` and `f` (the HBM latency cover).
+// x neighbours come from the adjacent lanes by DPP wave shifts (no memory), y neighbours inside the
+// strip are the lane's own registers, and only the strip's first and last row are exchanged with
+// the neighbouring wavefronts through LDS, once per colour phase (one barrier each).
+// Storing by colour instead of by row makes every lane update a point in every phase: which of the
+// two rows of a pair holds the lane's colour-c point depends on the lane's parity only.
+#include "mgrt_internal.h"
+#include <type_traits>
+#include <cstdlib>
+
+using namespace mgrt;
+
+namespace {
+
+constexpr int kWave = 64;
+
+// Neighbour-lane reads as DPP wave shifts: no memory, no `old` operand to initialise (lanes without
+// a source lane, 0 and 63, read 0; their columns are halo).
+__device__ __forceinline__ int dpp_lower(int v) { return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, true); } // wave_shr:1
+__device__ __forceinline__ int dpp_upper(int v) { return __builtin_amdgcn_mov_dpp(v, 0x130, 0xf, 0xf, true); } // wave_shl:1
+__device__ __forceinline__ float from_lower_lane(float v) { return __int_as_float(dpp_lower(__float_as_int(v))); }
+__device__ __forceinline__ float from_upper_lane(float v) { return __int_as_float(dpp_upper(__float_as_int(v))); }
+__device__ __forceinline__ double from_lower_lane(double v)
+{
+    const long long b = __double_as_longlong(v);
+    return __longlong_as_double(((long long)dpp_lower((int)(b >> 32)) << 32) | (unsigned)dpp_lower((int)b));
+}
+__device__ __forceinline__ double from_upper_lane(double v)
+{
+    const long long b = __double_as_longlong(v);
+    return __longlong_as_double(((long long)dpp_upper((int)(b >> 32)) << 32) | (unsigned)dpp_upper((int)b));
+}
+
+// Bijective map from the launch's block id to a tile id such that the blocks of one XCD (ids equal
+// mod 8) get consecutive tile ids.
+__device__ __forceinline__ int xcd_contiguous(int b, int nb)
+{
+    const int q = nb / 8, r = nb % 8, xcd = b % 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+}
+
+// Plane-relative buffer addressing: a descriptor per z plane (base = array + slab*z, all scalar
+// registers) plus a per-lane byte offset that never changes during the march.  Offsets at or past
+// the plane size are dropped by the hardware range check: loads return 0, stores do nothing, which
+// replaces every bounds branch.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t plane_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_load(float &v, rsrc_t r, unsigned off)
+{
+    v = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void buf_load(double &v, rsrc_t r, unsigned off)
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 t = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    v = __longlong_as_double(((long long)t.y << 32) | t.x);
+}
+// Stores are issued from inline asm so that the compiler's s_waitcnt bookkeeping sees loads only.
+// With loads and stores both outstanding it assumes they may complete out of order and waits with
+// vmcnt(0) before the first use of any prefetched plane, which drains the whole prefetch ring once
+// per unrolled group.  With the stores hidden it emits counted waits; the hardware counts the
+// hidden stores as well, so those waits are merely stricter than needed.  Nothing ever reads
+// `out` in this kernel, so the stores themselves need no wait.  The descriptor words come from
+// scalar ALU results, hence the wait states opening the string.
+typedef int desc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ desc_t plane_desc(const void *base, unsigned bytes)
+{
+    const unsigned long long a = (unsigned long long)base;
+    desc_t d;
+    d.x = (int)(unsigned)a;
+    d.y = (int)((unsigned)(a >> 32) & 0xffffu);
+    d.z = (int)bytes;
+    d.w = 0x00020000;
+    return d;
+}
+// Prefetch loads are hidden from the compiler as well: its own accounting across the unrolled
+// loop's back edge waits for all but the last plane requested, i.e. it keeps one plane in flight
+// instead of PF.  The loads below are followed, right before the first use of a prefetch slot, by
+// wait_slot<N>(), a counted s_waitcnt that names every register of the slot as read-write so that no
+// use can be scheduled above it.  N is the number of vector-memory operations (loads and hidden
+// stores alike: the hardware retires them in issue order) issued after the slot's loads.
+__device__ __forceinline__ void buf_load_hidden(float &v, desc_t r, unsigned off)
+{
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(off), "s"(r) : "memory");
+}
+__device__ __forceinline__ void buf_load_hidden(double &v, desc_t r, unsigned off)
+{
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(v) : "v"(off), "s"(r) : "memory");
+}
+template <int N, class R> __device__ __forceinline__ void wait_slot2(R &a, R &b, R &c, R &d)
+{
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N));
+}
+template <int N, class R, int SR> __device__ __forceinline__ void wait_slot(R (&u)[SR], R (&f)[SR])
+{
+    static_assert(SR % 2 == 0 && N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+#pragma unroll
+    for (int r = 0; r < SR; r += 2)
+        wait_slot2<N>(u[r], u[r + 1], f[r], f[r + 1]);
+}
+
+__device__ __forceinline__ void buf_store_hidden(float v, desc_t r, unsigned off)
+{
+    asm volatile("s_nop 4\n\tbuffer_store_dword %0, %1, %2, 0 offen" ::"v"(v), "v"(off), "s"(r) : "memory");
+}
+__device__ __forceinline__ void buf_store_hidden(double v, desc_t r, unsigned off)
+{
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, 0 offen" ::"v"(v), "v"(off), "s"(r) : "memory");
+}
+
+template <class R, int ITERS, int SR, int NW, int PFM, bool OMEGA1>
+__global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const R *__restrict__ in,
+                                                              R *__restrict__ out, const R *__restrict__ f,
+                                                              R omega, int zcount, int ntx)
+{
+    static_assert(SR % 2 == 0, "rows are handled in pairs");
+    constexpr int H = 2 * ITERS, J = SR / 2, ND = 2 * ITERS + 1;
+    // The plane rings (period ND) and the prefetch ring (period PF) are addressed with indices that
+    // are compile-time constants inside a time loop unrolled PF times, PF a multiple of ND: plane i
+    // lives in ring slot i % ND and prefetch slot i % PF, nothing is ever shifted.
+    constexpr int PF = PFM * ND;
+    constexpr int kYounger = SR + (PF - 1) * 3 * SR; // see wait_slot
+    static_assert(kYounger < 64, "too many vector-memory operations in flight for a counted wait");
+    constexpr int OX = kWave - 2 * H, OY = NW * SR - 2 * H;
+    __shared__ R bnd[2][ITERS][NW][2][kWave];
+
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    // Blocks are dealt to the 8 XCDs round-robin (block b and b+8 share an L2).  Give every XCD a
+    // contiguous run of tiles, so that the halo columns and the partial cache lines two
+    // neighbouring tiles both touch are fetched from HBM once and hit in that XCD's L2 the second
+    // time.  A speed matter only: any placement computes the same values.
+    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tx = tile % ntx, ty = tile / ntx;
+    const int x = tx * OX - H + lane;
+    const int ly0 = w * SR;               // first strip row inside the tile
+    const int y0 = ty * OY - H + ly0;     // its array row
+    const bool xin = x >= 0 && x < g.nx;
+    // which row of a pair holds this lane's colour-0 point: row 2j + s0
+    const int s0 = (x + y0 + g.y0) & 1;
+
+    // Per row: byte offset of the column inside a plane for loads (past the plane for lanes and
+    // rows outside the grid, which then read 0) and for stores (past the plane unless the point
+    // belongs to the tile's interior), and the class of the column when it does not depend on z
+    // (a lateral face, or OUTER outside the grid).
+    constexpr unsigned kDrop = 0x80000000u;
+    const unsigned plane_bytes = (unsigned)(g.pitch * (long long)g.ny * (long long)sizeof(R));
+    unsigned off[SR], soff[SR];
+    int rowcls[SR];
+#pragma unroll
+    for (int r = 0; r < SR; ++r) {
+        const int y = y0 + r, yg = y + g.y0;
+        const bool live = xin && y >= 0 && y < g.ny;
+        const bool keep = live && lane >= H && lane < kWave - H && ly0 + r >= H && ly0 + r < NW * SR - H;
+        const unsigned o = ((unsigned)x + (unsigned)g.pitch * (unsigned)y) * (unsigned)sizeof(R);
+        off[r] = live ? o : kDrop;
+        soff[r] = keep ? o : kDrop;
+        int c = -1;
+        if (!live) c = MGRT_CELL_OUTER;
+        else if (yg == 0) c = g.face[2];
+        else if (yg == g.gny - 1) c = g.face[3];
+        else if (x == 0) c = g.face[0];
+        else if (x == g.nx - 1) c = g.face[1];
+        rowcls[r] = c;
+    }
+    bool interior[2][J], latdir[2][J], latfix[2][J]; // latfix: lateral Dirichlet column
+#pragma unroll
+    for (int j = 0; j < J; ++j) { // row 2j + s0 of pair j holds the colour-0 point
+        const int c0 = s0 ? rowcls[2 * j + 1] : rowcls[2 * j];
+        const int c1 = s0 ? rowcls[2 * j] : rowcls[2 * j + 1];
+        interior[0][j] = c0 < 0;
+        interior[1][j] = c1 < 0;
+        latdir[0][j] = c0 == MGRT_CELL_DIRICHLET;
+        latdir[1][j] = c1 == MGRT_CELL_DIRICHLET;
+        latfix[0][j] = latdir[0][j] && !interior[0][j];
+        latfix[1][j] = latdir[1][j] && !interior[1][j];
+    }
+
+    R C[2][ND][J], F[2][ND][J];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int j = 0; j < J; ++j) C[c][d][j] = F[c][d][j] = 0;
+
+    const long long slab = g.slab;
+    const int zlast = g.nz - 1;
+    R pu[PF][SR], pf[PF][SR];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        const long long zo = slab * (k < zlast ? k : zlast);
+        const desc_t ru = plane_desc(in + zo, plane_bytes), rf = plane_desc(f + zo, plane_bytes);
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+            buf_load_hidden(pu[k][r], ru, off[r]);
+            buf_load_hidden(pf[k][r], rf, off[r]);
+        }
+    }
+    auto drain0 = [&]() {
+#pragma unroll
+        for (int k = 0; k < PF; ++k)
+            wait_slot<0>(pu[k], pf[k]);
+    };
+    drain0(); // the loop below starts from landed registers (see `drain`)
+
+    const int nsteps = g.nz + 2 * ITERS - 1; // planes entering the ring: 0 .. nz+2*ITERS-2
+    const int zlim = zcount < g.nz ? zcount : g.nz;
+    const int wu = w > 0 ? w - 1 : 0, wd = w + 1 < NW ? w + 1 : NW - 1;
+    // One group of PF consecutive time steps, unrolled so that every ring index is a constant.
+    // FAST groups are those whose steps all work on planes strictly between the z faces and below
+    // zlim, prefetch planes that exist, and store a plane: no per-step conditions are left and the
+    // class of a point is a per-lane constant.
+    auto group = [&](auto fast_tag, const int i0) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int i = i0 + u; // plane entering the ring; i0 is a multiple of ND
+            if (FAST || i < nsteps) {
+#define PH(d) ((((u) - (d)) % ND + ND) % ND) /* ring slot of depth d, i.e. of plane i - d */
+                // ---- plane i: prefetch registers -> ring slot -----------------------------------
+                // In a fast group every step issues 2*SR loads then SR stores, so the slot's loads
+                // have SR stores and PF-1 whole steps behind them; elsewhere steps may skip their
+                // stores, so wait for everything.
+                if (FAST)
+                    wait_slot<kYounger>(pu[u], pf[u]);
+                else
+                    wait_slot<0>(pu[u], pf[u]);
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const R a0 = pu[u][2 * j], a1 = pu[u][2 * j + 1];
+                    const R b0 = pf[u][2 * j], b1 = pf[u][2 * j + 1];
+                    C[0][PH(0)][j] = s0 ? a1 : a0;
+                    C[1][PH(0)][j] = s0 ? a0 : a1;
+                    F[0][PH(0)][j] = s0 ? b1 : b0;
+                    F[1][PH(0)][j] = s0 ? b0 : b1;
+                    // The slot's registers must be dead before they are requested again below:
+                    // pin the four selects above the refill (asm volatile statements keep their
+                    // order), otherwise the compiler keeps the old values alive in copies it makes
+                    // ahead of the wait.
+                    asm volatile("" : "+v"(C[0][PH(0)][j]), "+v"(C[1][PH(0)][j]), "+v"(F[0][PH(0)][j]), "+v"(F[1][PH(0)][j]));
+                }
+                { // plane i + PF -> prefetch slot u
+                    const int zn = i + PF;
+                    const long long zo = slab * (FAST || zn < zlast ? zn : zlast);
+                    const desc_t ru = plane_desc(in + zo, plane_bytes), rf = plane_desc(f + zo, plane_bytes);
+#pragma unroll
+                    for (int r = 0; r < SR; ++r) {
+                        buf_load_hidden(pu[u][r], ru, off[r]);
+                        buf_load_hidden(pf[u][r], rf, off[r]);
+                    }
+                }
+                const int t = i - 1;
+                // ---- two colour phases; iteration k works on plane t - 2(k-1), depth 2k-1 ------
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const bool sc = (s0 ^ c) != 0; // odd row of the pair holds the colour-c point
+                    // Publish the strip's first and last row of the planes being updated.  Only the
+                    // other colour is read by this phase, and wherever a neighbouring strip needs
+                    // the first (last) row, that row holds that colour.
+#pragma unroll
+                    for (int k = 1; k <= ITERS; ++k) {
+                        bnd[c][k - 1][w][0][lane] = C[c ^ 1][PH(2 * k - 1)][0];
+                        bnd[c][k - 1][w][1][lane] = C[c ^ 1][PH(2 * k - 1)][J - 1];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 1; k <= ITERS; ++k) {
+                        const int z = t - 2 * (k - 1);
+                        if (FAST || (z >= 0 && z < zlim)) {
+                            const R up = bnd[c][k - 1][wu][1][lane];
+                            const R dn = bnd[c][k - 1][wd][0][lane];
+                            const int zcls = z == 0 ? g.face[4] : (z == zlast ? g.face[5] : MGRT_CELL_INNER);
+                            const bool zin = zcls == MGRT_CELL_INNER, zdir = zcls == MGRT_CELL_DIRICHLET;
+#pragma unroll
+                            for (int j = 0; j < J; ++j) {
+                                const R o = C[c ^ 1][PH(2 * k - 1)][j]; // other colour, same pair
+                                const R xm = from_lower_lane(o), xp = from_upper_lane(o);
+                                const R below = j > 0 ? C[c ^ 1][PH(2 * k - 1)][j > 0 ? j - 1 : 0] : up;
+                                const R above = j + 1 < J ? C[c ^ 1][PH(2 * k - 1)][j + 1 < J ? j + 1 : 0] : dn;
+                                const R yp = sc ? above : o; // u[y+1]
+                                const R ym = sc ? o : below; // u[y-1]
+                                const R own = C[c][PH(2 * k - 1)][j];
+                                const R fv = F[c][PH(2 * k - 1)][j];
+                                // mg_1.cl:35-42: neighbours summed in R in this order, times the
+                                // double literal 1.0/6.0, rounded to R
+                                const R val = (1.0 / 6.0) *
+                                              (xp + xm + yp + ym + C[c][PH(2 * k - 2)][j] + C[c][PH(2 * k)][j] - fv);
+                                // mg_1.cl:69; for omega == 1 the double expression reduces exactly
+                                // to val + 0*own evaluated in R
+                                const R gs = OMEGA1 ? val + (R)0 * own : (R)(val * omega + (1.0 - omega) * own);
+                                const bool take_gs = FAST ? interior[c][j] : (interior[c][j] && zin);
+                                const bool take_f = FAST ? latfix[c][j] : (interior[c][j] ? zdir : latdir[c][j]);
+                                C[c][PH(2 * k - 1)][j] = take_gs ? gs : (take_f ? fv : own);
+                            }
+                        }
+                    }
+                }
+                // ---- plane t - 2(ITERS-1) is final: store the tile's interior -------------------
+                const int zf = t - 2 * (ITERS - 1);
+                if (FAST || zf >= 0) {
+                    const desc_t ro = plane_desc(out + slab * zf, plane_bytes);
+#pragma unroll
+                    for (int r = 0; r < SR; ++r)
+                        buf_store_hidden(((r & 1) ^ s0) ? C[1][PH(2 * ITERS - 1)][r / 2] : C[0][PH(2 * ITERS - 1)][r / 2],
+                                         ro, soff[r]);
+                }
+#undef PH
+            }
+        }
+    };
+
+    // Registers with a hidden load pending must not be touched before their wait.  Inside the fast
+    // loop that holds by construction (tools/check_hidden_loads.py audits the generated code for
+    // copies); everywhere else the compiler may copy loop-carried registers at a loop latch, so
+    // every other path drains all prefetches before it reaches one.
+    auto drain = [&]() {
+#pragma unroll
+        for (int k = 0; k < PF; ++k)
+            wait_slot<0>(pu[k], pf[k]);
+    };
+    // first step of a group: t - 2(ITERS-1) >= 1; last step: t < zlast, t < zlim, i + PF <= zlast
+    auto is_fast = [&](int i0) { return i0 >= 2 * ITERS && i0 + PF - 2 < zlim && i0 + 2 * PF - 1 <= zlast; };
+    // The fast groups run in a loop of their own: with a single path through the loop body the
+    // register allocator keeps every ring and prefetch register in place across the back edge
+    // (a shared loop made it copy the freshly requested prefetch registers at the latch, which
+    // forces a full vmcnt(0) drain per group).
+    for (int i0 = 0; i0 < nsteps;) {
+        if (is_fast(i0)) {
+            do {
+                group(std::true_type{}, i0);
+                i0 += PF;
+            } while (is_fast(i0));
+            drain();
+        } else {
+            group(std::false_type{}, i0);
+            i0 += PF;
+            drain();
+        }
+    }
+}
+
+template <class R, int ITERS, int SR, int NW, int PFM>
+mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, int zcount, hipStream_t hs)
+{
+    constexpr int H = 2 * ITERS, OX = kWave - 2 * H, OY = NW * SR - 2 * H;
+    static_assert(OY > 0, "tile has no interior");
+    const int ntx = (g->nx + OX - 1) / OX, nty = (g->ny + OY - 1) / OY;
+    const dim3 grid(ntx * nty);
+    if (omega == (R)1)
+        k_smooth3d_fused<R, ITERS, SR, NW, PFM, true><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, omega, zcount, ntx);
+    else
+        k_smooth3d_fused<R, ITERS, SR, NW, PFM, false><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, omega, zcount, ntx);
+    MGRT_HIP(hipGetLastError());
+    return MGRT_OK;
+}
+
+template <class R> struct Cfg;
+template <> struct Cfg<float> {
+    static constexpr int SR1 = 4, NW1 = 4, PF1 = 1; // one iteration per sweep: 3 planes prefetched
+    static constexpr int SR2 = 4, NW2 = 8, PF2 = 1; // two iterations per sweep: 5 planes prefetched
+};
+template <> struct Cfg<double> {
+    static constexpr int SR1 = 4, NW1 = 4, PF1 = 1;
+    static constexpr int SR2 = 2, NW2 = 12, PF2 = 1;
+};
+
+template <class R>
+mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, int iters, int zcount,
+                         mgrt_stream s)
+{
+    if (mgrt_status st = require_init()) return st;
+    if (mgrt_status st = check_grid(g, "mgrt_smooth_sweep")) return st;
+    MGRT_REQUIRE(out && in && f, "mgrt_smooth_sweep: null field");
+    MGRT_REQUIRE(out != in && out != f, "mgrt_smooth_sweep: out must not alias in or f");
+    MGRT_REQUIRE(zcount >= 0 && zcount <= g->nz, "mgrt_smooth_sweep: zcount %d outside [0,%d]", zcount, g->nz);
+    MGRT_REQUIRE(g->slab < (1LL << 30), "mgrt_smooth_sweep: plane too large for 32-bit in-plane offsets");
+    if (g->dim != 3)
+        return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep: 3D grids only");
+    if (g->cells)
+        return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep: byte cell maps are not supported, use mgrt_smooth_pass");
+    if (iters != 1 && iters != 2)
+        return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep: iters must be 1 or 2, got %d", iters);
+    hipStream_t hs = (hipStream_t)s;
+    using C = Cfg<R>;
+#ifdef MGRT_TUNE
+    // development only: pick a tile shape at run time
+    if (const char *e = getenv("MGRT_SWEEP_CFG")) {
+        const int c = atoi(e);
+        if (sizeof(R) == 4 && iters == 2) {
+            switch (c) {
+            case 1: return launch<R, 2, 4, 4, 1>(g, out, in, f, omega, zcount, hs);
+            case 2: return launch<R, 2, 4, 6, 1>(g, out, in, f, omega, zcount, hs);
+            case 3: return launch<R, 2, 2, 16, 1>(g, out, in, f, omega, zcount, hs);
+            case 4: return launch<R, 2, 2, 8, 1>(g, out, in, f, omega, zcount, hs);
+            case 5: return launch<R, 2, 4, 16, 1>(g, out, in, f, omega, zcount, hs);
+            case 6: return launch<R, 2, 2, 12, 1>(g, out, in, f, omega, zcount, hs);
+            }
+        }
+        if (sizeof(R) == 4 && iters == 1) {
+            switch (c) {
+            case 1: return launch<R, 1, 4, 8, 1>(g, out, in, f, omega, zcount, hs);
+            case 2: return launch<R, 1, 2, 8, 2>(g, out, in, f, omega, zcount, hs);
+            case 3: return launch<R, 1, 2, 16, 2>(g, out, in, f, omega, zcount, hs);
+            case 4: return launch<R, 1, 8, 4, 1>(g, out, in, f, omega, zcount, hs);
+            case 5: return launch<R, 1, 4, 16, 1>(g, out, in, f, omega, zcount, hs);
+            case 6: return launch<R, 1, 8, 8, 1>(g, out, in, f, omega, zcount, hs);
+            }
+        }
+    }
+#endif
+    if (iters == 1)
+        return launch<R, 1, C::SR1, C::NW1, C::PF1>(g, out, in, f, omega, zcount, hs);
+    return launch<R, 2, C::SR2, C::NW2, C::PF2>(g, out, in, f, omega, zcount, hs);
+}
+
+} // namespace
+
+extern "C" mgrt_status mgrt_smooth_sweep_f32(const mgrt_grid *g, float *out, const float *in, const float *f,
+                                             float omega, int iters, int zcount, mgrt_stream s)
+{
+    return smooth_sweep<float>(g, out, in, f, omega, iters, zcount, s);
+}
+
+extern "C" mgrt_status mgrt_smooth_sweep_f64(const mgrt_grid *g, double *out, const double *in, const double *f,
+                                             double omega, int iters, int zcount, mgrt_stream s)
+{
+    return smooth_sweep<double>(g, out, in, f, omega, iters, zcount, s);
+}

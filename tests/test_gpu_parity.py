@@ -122,6 +122,57 @@ def test_kernels_match_oracle(dev, mgo, dt, shape):
         assert L.linfnorm_reftree(du) == mgo.linfnorm_tree(u)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", [(9, 11, 13), (5, 5, 5), (3, 3, 3), (33, 17, 65), (20, 67, 129), (17, 130, 70),
+                                   (40, 60, 58), (6, 25, 121)],
+                         ids=lambda s: "x".join(map(str, s[::-1])))
+def test_fused_sweep_matches_oracle(dev, mgo, dt, shape):
+    """out = S^iters(in) in one z-march against 2*iters single-colour passes of the oracle."""
+    import torch
+    from multigrid_amd import _lib as L
+    rng = np.random.default_rng(abs(hash((shape, dt.__name__, "sweep"))) % 2**32)
+    for faces in ((2,) * 6, (2, 3, 3, 2, 2, 3), (3, 3, 2, 2, 1, 2)):
+        cell = mgo.box_cells(shape, faces)
+        g = L.grid(shape, faces=faces)
+        u = rng.standard_normal(shape).astype(dt)
+        f = rng.standard_normal(shape).astype(dt)
+        du, df = to_dev(u, dev), to_dev(f, dev)
+        for omega in (1.0, 0.8):
+            for iters in (1, 2):
+                for zc in (shape[0], (shape[0] + 1) // 2, 1):
+                    ref = u.copy()
+                    for _ in range(iters):
+                        mgo.smooth_pass(cell, ref, f, dt(omega), 0, zc)
+                        mgo.smooth_pass(cell, ref, f, dt(omega), 1, zc)
+                    out = torch.full_like(du, 99.0)
+                    L.smooth_sweep(g, out, du, df, omega, iters, zc)
+                    assert bits_equal(out.cpu().numpy(), ref), (faces, omega, iters, zc)
+    assert torch.equal(du.cpu(), torch.from_numpy(u))  # the input is not modified
+
+
+def test_fused_sweep_on_a_slab(dev):
+    """Rows of a y-slab (odd global offset, so the colours are shifted) equal the whole-grid rows
+    wherever the halo of 2*iters rows was available."""
+    import torch
+    from multigrid_amd import _lib as L
+    shape = (17, 41, 37)
+    torch.manual_seed(11)
+    u = torch.randn(shape, device=dev)
+    f = torch.randn(shape, device=dev)
+    g = L.grid(shape)
+    for iters in (1, 2):
+        whole = torch.empty_like(u)
+        L.smooth_sweep(g, whole, u, f, 0.9, iters)
+        h = 2 * iters
+        y0, y1 = 7, 30
+        sl = slice(y0 - h, y1 + h)
+        us, fs = u[:, sl, :].contiguous(), f[:, sl, :].contiguous()
+        gs = L.grid(tuple(us.shape), y0=y0 - h, gny=shape[1])
+        outs = torch.empty_like(us)
+        L.smooth_sweep(gs, outs, us, fs, 0.9, iters)
+        assert torch.equal(outs[:, h:-h, :], whole[:, y0:y1, :])
+
+
 def test_norms_are_deterministic(dev):
     import torch
     from multigrid_amd import _lib as L
@@ -135,7 +186,7 @@ def test_norms_are_deterministic(dev):
     assert outs[0] == outs[1] == outs[2]
 
 
-def run_plan(dev, g, use_graph=False):
+def run_plan(dev, g, use_graph=False, no_fuse=False):
     import torch
     from multigrid_amd import _lib as L
     f = g["func"]
@@ -145,7 +196,7 @@ def run_plan(dev, g, use_graph=False):
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         df = to_dev(f, dev)
-        plan = L.Plan(shape, tdt, zfull=bool(zfull), use_graph=use_graph)
+        plan = L.Plan(shape, tdt, zfull=bool(zfull), use_graph=use_graph, no_fuse=no_fuse)
         if str(g["mode"]) == "mg":
             du = torch.zeros(shape, dtype=tdt, device=dev)
             hist = plan.vcycle(du, df, float(g["omega"]), a1, a2, v, cycles, history=True)
@@ -177,6 +228,15 @@ def test_cycles_match_golden(dev, path):
     # exact norm: the summation order differs from the oracle's serial loop, not the values summed
     assert np.allclose(hist, ref_h, rtol=1e-11, atol=0)
     assert tree[0] == g["l2res_tree"] and tree[1] == g["linfres_tree"]
+
+
+@pytest.mark.parametrize("path", [p for p in GOLDEN if "/3d_" in p],
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_unfused_cycles_match_golden(dev, path):
+    """The one-launch-per-colour-pass schedule (no_fuse) gives the same bits as the fused sweeps."""
+    g = np.load(path)
+    _, u, _ = run_plan(dev, g, no_fuse=True)
+    assert bits_equal(u, g["u"])
 
 
 @pytest.mark.parametrize("name", ["3d_33_f32_v22_zfull", "2d_65_f64_v22", "3d_17_f32_fmg_default"])

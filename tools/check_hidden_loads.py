@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Audit of the fused smoother's generated code: loads issued from inline asm are invisible to the
+compiler, so a register with such a load pending must not be read by compiler-generated code before
+the kernel's own s_waitcnt.  The source guarantees this everywhere except inside the inner
+(fast) time loop, where it depends on the register allocator not copying the prefetch registers.
+This script compiles the file to assembly and fails if, inside any depth-2 loop of a
+k_smooth3d_fused kernel, a compiler-generated instruction reads a register that an asm load in
+that loop writes, other than after an asm wait that follows the load... approximated as: no plain
+register copy (v_mov / v_accvgpr / scratch) of such a register anywhere in the loop.
+
+Usage: tools/check_hidden_loads.py [hipcc flags...]   (exit status 1 on a finding)"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "multigrid_amd", "csrc", "mgrt_smooth_fused.hip")
+
+
+def regs(tok):
+    """v12 or v[12:13] -> {12, 13}"""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "fused.s")
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+               "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out, SRC] + sys.argv[1:]
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        text = open(out).read().splitlines()
+    kernel, bad, nk, loops = None, [], 0, 0
+    in_asm, depth2 = False, False
+    loop_lines = []
+
+    def flush():
+        nonlocal loop_lines, loops
+        if not loop_lines:
+            return
+        loops += 1
+        dests = set()
+        for asm, line in loop_lines:
+            m = re.match(r"\s*buffer_load_dword(?:x2)?\s+(\S+),", line)
+            if asm and m:
+                dests |= regs(m.group(1))
+        for asm, line in loop_lines:
+            if asm:
+                continue
+            m = re.match(r"\s*(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32|scratch_store\S*)\s+(.*)", line)
+            if not m:
+                continue
+            ops = [o.strip() for o in m.group(2).split(",")]
+            srcs = set().union(*[regs(o) for o in ops[1:]]) if len(ops) > 1 else set()
+            if srcs & dests:
+                bad.append((kernel, line.strip()))
+        loop_lines = []
+
+    for line in text:
+        m = re.match(r"^(_Z\S*k_smooth3d_fused\S*):", line)
+        if m:
+            flush()
+            kernel, depth2 = m.group(1), False
+            nk += 1
+            continue
+        if kernel is None:
+            continue
+        if "s_endpgm" in line:
+            flush()
+            kernel = None
+            continue
+        if ";;#ASMSTART" in line:
+            in_asm = True
+            continue
+        if ";;#ASMEND" in line:
+            in_asm = False
+            continue
+        if re.match(r"^\.LBB\d+_\d+:", line):
+            # block labels carry the loop annotation on this or the next comment line
+            depth2_here = "Depth=2" in line
+            if not depth2_here and depth2 and "Depth=1" in line:
+                flush()
+                depth2 = False
+            if depth2_here:
+                depth2 = True
+        elif "Inner Loop Header: Depth=2" in line or ("in Loop:" in line and "Depth=2" in line):
+            depth2 = True
+        if depth2:
+            loop_lines.append((in_asm, line))
+    flush()
+    if nk == 0 or loops == 0:
+        print("check_hidden_loads: found %d kernels, %d inner loops -- the audit did not run" % (nk, loops))
+        return 1
+    for k, l in bad:
+        print("check_hidden_loads: %s: copy of a register with a hidden load pending: %s" % (k[:70], l))
+    print("check_hidden_loads: %d kernels, %d inner loops, %d findings" % (nk, loops, len(bad)))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
