@@ -18,7 +18,7 @@ all: lib oracle host
 
 lib: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/mgrt_internal.h include/mgrt.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/mgrt_internal.h $(CSRC)/mgrt_device.h include/mgrt.h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 $(LIB): $(LIB_OBJS)

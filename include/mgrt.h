@@ -121,6 +121,13 @@ mgrt_status mgrt_box_cells_host(int dim, int nx, int ny, int nz, const int face[
        reduction_kernel (mg_1.cl:146-190, mg_0.cl:139-157).  Coarse rows cylo <= j < cyhi. */     \
     mgrt_status mgrt_restrict##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc,            \
                                  const R *rf, int cylo, int cyhi, mgrt_stream s);                  \
+    /* rc = Restrict(f - A u) in one pass that never writes the fine residual: the results of       \
+       mgrt_residual (with zero_unwritten) followed by mgrt_restrict.  Replaces the kernel pair     \
+       launched by MultigridSolver3D::iterate (multigridsolver3D.cpp:61-64).  3D grids with odd     \
+       extents only (MGRT_E_UNSUPPORTED otherwise). */                                              \
+    mgrt_status mgrt_residual_restrict##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc,   \
+                                          const R *u, const R *f, int cylo, int cyhi,              \
+                                          mgrt_stream s);                                          \
     /* out = u + 4*P(e), P bi/trilinear, injection on border cells; out may alias u.  Replaces    \
        residual_correct_kernel (mg_1.cl:200-233, mg_0.cl:167-194). */                             \
     mgrt_status mgrt_correct##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *out,            \

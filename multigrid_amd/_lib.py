@@ -40,7 +40,7 @@ class PlanDesc(C.Structure):
 
 
 # every symbol include/mgrt.h declares; checked by the CPU test-suite against the header
-_KERNELS = ["smooth_pass", "smooth", "smooth_sweep", "residual", "restrict", "correct", "prolong", "zero_outside",
+_KERNELS = ["smooth_pass", "smooth", "smooth_sweep", "residual", "restrict", "residual_restrict", "correct", "prolong", "zero_outside",
             "diff", "sumsq", "maxabs", "l2norm_reftree", "linfnorm_reftree"]
 _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "upload", "download",
             "stream_create", "stream_destroy", "sync", "zero", "box_cells_host",
@@ -89,6 +89,7 @@ def load():
             "smooth_sweep": [G, p, p, p, r, i, i, p],
             "residual": [G, p, p, p, i, p, i, i, p],
             "restrict": [G, G, p, p, i, i, p],
+            "residual_restrict": [G, G, p, p, p, i, i, p],
             "correct": [G, G, p, p, p, i, i, p],
             "prolong": [G, G, p, p, i, i, p],
             "zero_outside": [G, p, p],
@@ -186,6 +187,11 @@ def residual(g, r, u, f, zero_unwritten=False, norm2=None, ylo=0, yhi=None, stre
 def restrict(gf, gc, rc, rf, cylo=0, cyhi=None, stream=None):
     check(_fn("restrict", rf)(C.byref(gf), C.byref(gc), _p(rc), _p(rf), cylo, gc.ny if cyhi is None else cyhi,
                               _stream(stream)))
+
+
+def residual_restrict(gf, gc, rc, u, f, cylo=0, cyhi=None, stream=None):
+    check(_fn("residual_restrict", u)(C.byref(gf), C.byref(gc), _p(rc), _p(u), _p(f), cylo,
+                                      gc.ny if cyhi is None else cyhi, _stream(stream)))
 
 
 def correct(gf, gc, out, u, e, ylo=0, yhi=None, stream=None):

@@ -41,6 +41,15 @@ mgrt_status check_grid(const mgrt_grid *g, const char *who);
 
 constexpr int kMaxPartials = 1 << 16;
 
+// Blocks are dealt to the 8 XCDs round-robin (blocks b and b+8 share an L2).  This bijective map
+// gives the blocks of one XCD consecutive work-item ids, so that neighbouring tiles, which touch
+// the same halo cells and cache lines, meet in one L2.  A speed matter only.
+__device__ __forceinline__ int xcd_contiguous(int b, int nb)
+{
+    const int q = nb / 8, r = nb % 8, xcd = b % 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+}
+
 } // namespace mgrt
 
 #endif

@@ -8,6 +8,7 @@
 // Wavefronts are 64 wide; blocks are one or four wavefronts.  All kernels are HBM-bound stencils:
 // no matrix cores.
 #include "mgrt_internal.h"
+#include "mgrt_device.h"
 
 using namespace mgrt;
 
@@ -190,15 +191,19 @@ template <bool MAX> __global__ __launch_bounds__(256) void k_fold_partials(const
 template <class R, int DIM, bool MAP, bool NORM, int ZC>
 __global__ __launch_bounds__(256) void k_residual(mgrt_grid g, R *r, const R *__restrict__ u,
                                                   const R *__restrict__ f, int zero_unwritten,
-                                                  double *partials, int ylo, int yhi)
+                                                  double *partials, int ylo, int yhi, unsigned nbxy)
 {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool live = idx < (long long)g.nx * (yhi - ylo);
+    // 1D launch, z chunk slowest, handed out XCD-contiguously: the rows y-1/y+1 and the chunk's
+    // two halo planes are then found in the L2 of the XCD that fetched them for a neighbour block.
+    const unsigned bid = (unsigned)xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const unsigned bxy = bid % nbxy, bz = bid / nbxy;
+    const unsigned idx = bxy * 256u + threadIdx.x;
+    const bool live = idx < (unsigned)g.nx * (unsigned)(yhi - ylo);
     double acc = 0;
     if (live) {
-        const int y = ylo + (int)(idx / g.nx), x = (int)(idx % g.nx);
+        const int y = ylo + (int)(idx / (unsigned)g.nx), x = (int)(idx % (unsigned)g.nx);
         const long long p = g.pitch, s = g.slab;
-        const int zb = DIM == 3 ? blockIdx.y * ZC : 0;
+        const int zb = DIM == 3 ? (int)bz * ZC : 0;
         const int ze = DIM == 3 ? (zb + ZC < g.nz ? zb + ZC : g.nz) : 1;
         long long b = x + p * y + s * zb;
         R um = (DIM == 3 && zb > 0) ? u[b - s] : (R)0;
@@ -228,7 +233,97 @@ __global__ __launch_bounds__(256) void k_residual(mgrt_grid g, R *r, const R *__
         }
     }
     if (NORM)
-        block_reduce_store<false, 4>(acc, partials + blockIdx.x + (size_t)gridDim.x * blockIdx.y);
+        block_reduce_store<false, 4>(acc, partials + bid);
+}
+
+// 3D residual with 16 bytes per lane: a thread owns VX consecutive x of one row (4 floats or 2
+// doubles) and walks a chunk of planes.  A read path fed with 4-byte loads tops out near 4 TB/s on
+// this chip and 8- or 16-byte loads reach 6.2-6.4 (rows need not be 16-byte aligned); per point
+// this kernel issues 7/VX wide memory instructions instead of 8 narrow ones.  Same expression and
+// operand order as k_residual.
+template <class R, int VX> struct alignas(sizeof(R)) VecU {
+    R v[VX];
+};
+template <class R, int VX> __device__ __forceinline__ void load_vec(R (&d)[VX], const R *p, int nval)
+{
+    if (nval == VX) {
+        const VecU<R, VX> t = *reinterpret_cast<const VecU<R, VX> *>(p);
+#pragma unroll
+        for (int e = 0; e < VX; ++e) d[e] = t.v[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < VX; ++e) d[e] = e < nval ? p[e] : (R)0;
+    }
+}
+
+template <class R, bool MAP, bool NORM, int ZC>
+__global__ __launch_bounds__(256) void k_residual3d_v(mgrt_grid g, R *r, const R *__restrict__ u,
+                                                      const R *__restrict__ f, int zero_unwritten,
+                                                      double *partials, int ylo, int yhi, unsigned nbxy)
+{
+    constexpr int VX = 16 / (int)sizeof(R);
+    const unsigned bid = (unsigned)xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const unsigned bxy = bid % nbxy, bz = bid / nbxy;
+    const unsigned nvx = ((unsigned)g.nx + VX - 1) / VX;
+    const unsigned idx = bxy * 256u + threadIdx.x;
+    const bool live = idx < nvx * (unsigned)(yhi - ylo);
+    double acc = 0;
+    if (live) {
+        const int y = ylo + (int)(idx / nvx), x0 = (int)(idx % nvx) * VX;
+        const int nval = g.nx - x0 < VX ? g.nx - x0 : VX;
+        const long long p = g.pitch, s = g.slab;
+        const int zb = (int)bz * ZC, ze = zb + ZC < g.nz ? zb + ZC : g.nz;
+        const bool has_ym = y > 0, has_yp = y + 1 < g.ny, has_l = x0 > 0, has_r = x0 + VX < g.nx;
+        long long b = x0 + p * y + s * zb;
+        R um[VX], uc[VX], up[VX], fv[VX], ym[VX], yp[VX];
+#pragma unroll
+        for (int e = 0; e < VX; ++e) um[e] = 0;
+        if (zb > 0) load_vec<R, VX>(um, u + b - s, nval);
+        load_vec<R, VX>(uc, u + b, nval);
+        for (int z = zb; z < ze; ++z, b += s) {
+#pragma unroll
+            for (int e = 0; e < VX; ++e) up[e] = ym[e] = yp[e] = 0;
+            if (z + 1 < g.nz) load_vec<R, VX>(up, u + b + s, nval);
+            load_vec<R, VX>(fv, f + b, nval);
+            if (has_ym) load_vec<R, VX>(ym, u + b - p, nval);
+            if (has_yp) load_vec<R, VX>(yp, u + b + p, nval);
+            const R left = has_l ? u[b - 1] : (R)0, right = has_r ? u[b + VX] : (R)0;
+            R out[VX];
+            bool wr[VX];
+            bool all = nval == VX;
+#pragma unroll
+            for (int e = 0; e < VX; ++e) {
+                const R xm = e == 0 ? left : uc[e > 0 ? e - 1 : 0];
+                const R xp = e == VX - 1 ? right : uc[e + 1 < VX ? e + 1 : 0];
+                const int t = e < nval ? cell_class<3, MAP>(g, x0 + e, y, z) : MGRT_CELL_OUTER;
+                const R vi = fv[e] - (xp + xm + yp[e] + ym[e] + up[e] + um[e] - 6 * uc[e]);
+                const R vd = fv[e] - uc[e];
+                wr[e] = t == MGRT_CELL_INNER || t == MGRT_CELL_DIRICHLET;
+                out[e] = t == MGRT_CELL_INNER ? vi : (t == MGRT_CELL_DIRICHLET ? vd : (R)0);
+                if (NORM && wr[e])
+                    acc += (double)out[e] * (double)out[e];
+                all = all && (wr[e] || zero_unwritten);
+            }
+            if (all) {
+                VecU<R, VX> t;
+#pragma unroll
+                for (int e = 0; e < VX; ++e) t.v[e] = out[e];
+                *reinterpret_cast<VecU<R, VX> *>(r + b) = t;
+            } else {
+#pragma unroll
+                for (int e = 0; e < VX; ++e)
+                    if (e < nval && (wr[e] || zero_unwritten))
+                        r[b + e] = out[e];
+            }
+#pragma unroll
+            for (int e = 0; e < VX; ++e) {
+                um[e] = uc[e];
+                uc[e] = up[e];
+            }
+        }
+    }
+    if (NORM)
+        block_reduce_store<false, 4>(acc, partials + bid);
 }
 
 // ---- full-weighting restriction (mg_1.cl:146-190, mg_0.cl:139-157) ----------------------------
@@ -236,21 +331,26 @@ __global__ __launch_bounds__(256) void k_residual(mgrt_grid g, R *r, const R *__
 // global row 2*jg.
 template <class R, int DIM, bool MAP>
 __global__ __launch_bounds__(256) void k_restrict(mgrt_grid fg, mgrt_grid cg, R *rc, const R *__restrict__ rf,
-                                                  int cylo, int cyhi)
+                                                  int cylo, int cyhi, unsigned nbxy)
 {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)cg.nx * (cyhi - cylo))
+    const unsigned bid = (unsigned)xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const unsigned idx = (bid % nbxy) * 256u + threadIdx.x;
+    if (idx >= (unsigned)cg.nx * (unsigned)(cyhi - cylo))
         return;
-    const int j = cylo + (int)(idx / cg.nx), i = (int)(idx % cg.nx);
-    const int k = DIM == 3 ? blockIdx.y : 0;
+    const int j = cylo + (int)(idx / (unsigned)cg.nx), i = (int)(idx % (unsigned)cg.nx);
+    const int k = DIM == 3 ? (int)(bid / nbxy) : 0;
     const int x = 2 * i, y = 2 * (j + cg.y0) - fg.y0, z = 2 * k;
     const long long p = fg.pitch, s = fg.slab;
     const R *c = rf + x + p * y + s * z;
     const long long d = i + (long long)cg.pitch * j + cg.slab * k;
 
     // forward 2x2(x2) block, tested in the reference's short-circuit order; cells past the far
-    // faces are never classified because the first test already hits the face
-    bool border = is_border(cell_class<DIM, MAP>(fg, x, y, z));
+    // faces are never classified because the first test already hits the face.  A centre on a face
+    // of the grid always injects: the reference would weight cells outside its arrays there if the
+    // face carried a non-border class.
+    const bool on_face = x == 0 || x == fg.nx - 1 || y + fg.y0 == 0 || y + fg.y0 == fg.gny - 1 ||
+                         (DIM == 3 && (z == 0 || z == fg.nz - 1));
+    bool border = on_face || is_border(cell_class<DIM, MAP>(fg, x, y, z));
     if (!border) {
         border = is_border(cell_class<DIM, MAP>(fg, x + 1, y, z)) ||
                  is_border(cell_class<DIM, MAP>(fg, x, y + 1, z)) ||
@@ -272,6 +372,172 @@ __global__ __launch_bounds__(256) void k_restrict(mgrt_grid fg, mgrt_grid cg, R 
     } else {
         rc[d] = 1.0 / 16.0 * (c[-p - 1] + c[-p + 1] + c[p - 1] + c[p + 1]) +
                 1.0 / 8.0 * (c[-p] + c[1] + c[-1] + c[p]) + 1.0 / 4.0 * (c[0]);
+    }
+}
+
+// ---- residual fused with its restriction (3D) ---------------------------------------------------
+// rc = Restrict(f - A u) without ever writing the fine residual: the V-cycle consumes the residual
+// only through the restriction (multigridsolver3D.cpp:61-64), so its N values need not travel to
+// HBM and back.  One thread owns one fine column of a 64 x 9 residual tile and walks a chunk of
+// fine planes with u[z-1], u[z], u[z+1] in registers; every residual plane goes into a 4-deep LDS
+// ring, and after each odd plane 2K+1 the first 31 x 4 threads form coarse plane K from planes
+// 2K-1, 2K, 2K+1 of the ring.  Expressions and operand order are those of residual_kernel
+// (mg_1.cl:46-53,111-133) and reduction_kernel (mg_1.cl:146-190); residual cells the reference
+// never writes (outer, Neumann) count as 0.
+constexpr int kRRX = 64, kRRY = 9, kRRCX = 31, kRRCY = 4;
+template <class R, bool MAP, int KC>
+__global__ __launch_bounds__(kRRX *kRRY) void k_residual_restrict3d(mgrt_grid fg, mgrt_grid cg, R *rc,
+                                                                    const R *__restrict__ u,
+                                                                    const R *__restrict__ f, int cylo, int cyhi,
+                                                                    int ntx, int nty)
+{
+    __shared__ R ring[4][kRRY][kRRX];
+    const int ntiles = ntx * nty;
+    const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int kchunk = t / ntiles, tile = t % ntiles;
+    const int lx = threadIdx.x % kRRX, ly = threadIdx.x / kRRX;
+    const int I0 = (tile % ntx) * kRRCX;
+    const int J0g = cylo + cg.y0 + (tile / ntx) * kRRCY; // global coarse row of the tile's first row
+    const int x = 2 * I0 - 1 + lx;
+    const int y = 2 * J0g - 1 + ly - fg.y0; // local fine row
+    const bool live = x >= 0 && x < fg.nx && y >= 0 && y < fg.ny;
+    const int kb = kchunk * KC, ke = kb + KC < cg.nz ? kb + KC : cg.nz;
+    // fine planes whose residual is needed: 2kb-1 .. 2(ke-1)+1, clipped to the grid
+    const int zb = 2 * kb - 1 > 0 ? 2 * kb - 1 : 0;
+    const int ze = 2 * (ke - 1) + 1 < fg.nz - 1 ? 2 * (ke - 1) + 1 : fg.nz - 1;
+
+    // Plane-relative buffer addressing (see mgrt_device.h): a descriptor per plane in scalar
+    // registers, per-thread byte offsets that never change.  Threads outside the grid use an
+    // offset past the plane, which loads 0; a neighbour offset that leaves the row is only ever
+    // formed for a column on a face, whose cells are not inner and ignore it.
+    constexpr unsigned kDrop = 0x80000000u;
+    const unsigned w = (unsigned)sizeof(R), pb = (unsigned)fg.pitch * w;
+    const unsigned plane_bytes = (unsigned)(fg.pitch * (long long)fg.ny) * w;
+    const unsigned oc = live ? ((unsigned)x + (unsigned)fg.pitch * (unsigned)y) * w : kDrop;
+    const unsigned oxp = live ? oc + w : kDrop, oxm = live ? oc - w : kDrop;
+    const unsigned oyp = live ? oc + pb : kDrop, oym = live ? oc - pb : kDrop;
+    // class of the column where it does not depend on z (lateral face, or OUTER outside), else -1
+    int colcls = -1;
+    if (!live) colcls = MGRT_CELL_OUTER;
+    else if (!MAP) {
+        const int yg = y + fg.y0;
+        if (yg == 0) colcls = fg.face[2];
+        else if (yg == fg.gny - 1) colcls = fg.face[3];
+        else if (x == 0) colcls = fg.face[0];
+        else if (x == fg.nx - 1) colcls = fg.face[1];
+    }
+    const bool col_z = colcls < 0, col_dir = colcls == MGRT_CELL_DIRICHLET;
+    const unsigned char *cellp = MAP && live ? fg.cells + x + (long long)fg.pitch * y : nullptr;
+
+    R um = 0, uc = 0;
+    {
+        const rsrc_t r0 = plane_rsrc(u + fg.slab * zb, plane_bytes);
+        buf_load(uc, r0, oc);
+        if (zb > 0) {
+            const rsrc_t rm = plane_rsrc(u + fg.slab * (zb - 1), plane_bytes);
+            buf_load(um, rm, oc);
+        }
+    }
+
+    // Coarse points are formed by groups of four lanes: lane 0 sums the 8 corners, lane 1 the 12
+    // edges, lane 2 the 6 faces (each in the reference's operand order), lane 3 idles; lane 0 then
+    // combines them.  This spreads the 27 LDS reads of a coarse point over three lanes and over
+    // eight of the block's nine waves instead of leaving them to two.
+    const int cpt = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int ci = I0 + cpt % kRRCX, cjl = cpt / kRRCX;
+    const int cj = J0g - cg.y0 + cjl;
+    const bool coarse_thread = cpt < kRRCX * kRRCY && ci < cg.nx && cj < cyhi && cj < cg.ny;
+    const int X = 2 * (ci - I0) + 1, Y = 2 * (cjl < kRRCY ? cjl : 0) + 1; // (2I, 2J) inside the tile
+    const int fx = 2 * ci, fy = 2 * (cj + cg.y0) - fg.y0;
+    const bool lat_face = fx == 0 || fx == fg.nx - 1 || fy + fg.y0 == 0 || fy + fg.y0 == fg.gny - 1;
+
+    // Loads run PFD planes ahead of the arithmetic, in registers whose indices are constants after
+    // unrolling.  The coarse store below is hidden from the compiler's wait-count bookkeeping (see
+    // mgrt_device.h): a visible store among the loads would make every wait a full drain.
+    constexpr int PFD = 3;
+    R pup[PFD], pfv[PFD], pxp[PFD], pxm[PFD], pyp[PFD], pym[PFD];
+    auto fetch = [&](int slot, int z) {
+        const int zc = z <= ze ? z : ze;
+        const rsrc_t ru = plane_rsrc(u + fg.slab * zc, plane_bytes), rf = plane_rsrc(f + fg.slab * zc, plane_bytes);
+        const rsrc_t rup = plane_rsrc(u + fg.slab * (zc + 1 < fg.nz ? zc + 1 : zc), plane_bytes);
+        buf_load(pup[slot], rup, oc);
+        buf_load(pfv[slot], rf, oc);
+        buf_load(pxp[slot], ru, oxp);
+        buf_load(pxm[slot], ru, oxm);
+        buf_load(pyp[slot], ru, oyp);
+        buf_load(pym[slot], ru, oym);
+    };
+#pragma unroll
+    for (int k = 0; k < PFD; ++k)
+        fetch(k, zb + k);
+
+    for (int z0 = zb; z0 <= ze; z0 += PFD) {
+#pragma unroll
+      for (int slot = 0; slot < PFD; ++slot) {
+        const int z = z0 + slot;
+        if (z > ze)
+            break;
+        const R up = pup[slot], fv = pfv[slot], xp = pxp[slot], xm = pxm[slot], yp = pyp[slot], ym = pym[slot];
+        fetch(slot, z + PFD);
+        int c;
+        if (MAP)
+            c = live ? cellp[fg.slab * z] : MGRT_CELL_OUTER;
+        else
+            c = col_z ? (z == 0 ? fg.face[4] : (z == fg.nz - 1 ? fg.face[5] : MGRT_CELL_INNER)) : colcls;
+        (void)col_dir;
+        const R ri = fv - (xp + xm + yp + ym + up + um - 6 * uc);
+        const R rd = fv - uc;
+        const R r = c == MGRT_CELL_INNER ? ri : (c == MGRT_CELL_DIRICHLET ? rd : (R)0);
+        um = uc;
+        uc = up;
+        ring[z & 3][ly][lx] = r;
+        __syncthreads();
+        if ((z & 1) && coarse_thread) {
+            const int k = z >> 1; // planes 2k-1, 2k, 2k+1 are in the ring
+            if (k >= kb && k < ke) {
+                const int fz = 2 * k;
+                const R(*m)[kRRX] = ring[(fz - 1) & 3]; // plane below
+                const R(*c0)[kRRX] = ring[fz & 3];
+                const R(*q)[kRRX] = ring[(fz + 1) & 3]; // plane above
+                R part_sum;
+                if (part == 0)
+                    part_sum = q[Y + 1][X + 1] + q[Y + 1][X - 1] + q[Y - 1][X + 1] + q[Y - 1][X - 1] + m[Y + 1][X + 1] +
+                               m[Y + 1][X - 1] + m[Y - 1][X + 1] + m[Y - 1][X - 1];
+                else if (part == 1)
+                    part_sum = c0[Y + 1][X + 1] + c0[Y + 1][X - 1] + c0[Y - 1][X + 1] + c0[Y - 1][X - 1] + m[Y + 1][X] +
+                               m[Y - 1][X] + m[Y][X + 1] + m[Y][X - 1] + q[Y + 1][X] + q[Y - 1][X] + q[Y][X + 1] +
+                               q[Y][X - 1];
+                else
+                    part_sum = c0[Y + 1][X] + c0[Y - 1][X] + c0[Y][X + 1] + c0[Y][X - 1] + q[Y][X] + m[Y][X];
+                // lanes 4n+1 and 4n+2 hand their sums to lane 4n
+                const R edges = __shfl_down(part_sum, 1, 4), faces = __shfl_down(part_sum, 2, 4);
+                if (part == 0) {
+                    // A centre on a face of the grid always injects (see k_restrict); otherwise the
+                    // forward 2x2x2 block is classified in the reference's short-circuit order.
+                    bool border = lat_face || fz == 0 || fz == fg.nz - 1 || is_border(cell_class<3, MAP>(fg, fx, fy, fz));
+                    if (!border)
+                        border = is_border(cell_class<3, MAP>(fg, fx + 1, fy, fz)) ||
+                                 is_border(cell_class<3, MAP>(fg, fx, fy + 1, fz)) ||
+                                 is_border(cell_class<3, MAP>(fg, fx + 1, fy + 1, fz)) ||
+                                 is_border(cell_class<3, MAP>(fg, fx, fy, fz + 1)) ||
+                                 is_border(cell_class<3, MAP>(fg, fx + 1, fy, fz + 1)) ||
+                                 is_border(cell_class<3, MAP>(fg, fx, fy + 1, fz + 1)) ||
+                                 is_border(cell_class<3, MAP>(fg, fx + 1, fy + 1, fz + 1));
+                    const R centre = c0[Y][X];
+                    const R v = border ? centre
+                                       : (R)(1.0 / 64.0 * part_sum + 1.0 / 32.0 * edges + 1.0 / 16.0 * faces +
+                                             1.0 / 8.0 * centre);
+                    store_hidden(rc + (ci + (long long)cg.pitch * cj + cg.slab * k), v);
+                }
+            }
+        }
+      }
+    }
+    // The last coarse plane of an odd-extent grid sits on the top face: injection.
+    if (ke == cg.nz && coarse_thread && part == 0) {
+        const int k = cg.nz - 1;
+        if (2 * k == fg.nz - 1 && k >= kb)
+            rc[ci + (long long)cg.pitch * cj + cg.slab * k] = ring[(2 * k) & 3][Y][X];
     }
 }
 
@@ -335,6 +601,80 @@ __global__ __launch_bounds__(256) void k_interp(mgrt_grid fg, mgrt_grid cg, R *o
         }
     }
     out[d] = MODE == 0 ? u[d] + val * 4 : val;
+}
+
+// 3D interpolation as a z-march: one thread owns fine column x of the fine row pair (2j, 2j+1) and
+// walks a chunk of coarse planes, carrying the four coarse values of plane k+1 over as plane k of
+// the next step.  Per four fine points that is 4 coarse loads instead of 32, and the fine field is
+// read and written in full coalesced rows.  Same expressions, same operand order as k_interp.
+template <class R, bool MAP, int MODE, int ZC>
+__global__ __launch_bounds__(256) void k_interp3d_march(mgrt_grid fg, mgrt_grid cg, R *out, const R *u,
+                                                        const R *__restrict__ e, int ylo, int yhi, int ntx, int nty)
+{
+    const int ntiles = ntx * nty;
+    const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int zc = t / ntiles, tile = t % ntiles;
+    const int x = (tile % ntx) * 64 + (threadIdx.x & 63);
+    // global coarse row handled by this thread; its fine rows are 2*cjg and 2*cjg+1
+    const int cjg = (ylo + fg.y0) / 2 + (tile / ntx) * 4 + (threadIdx.x >> 6);
+    if (x >= fg.nx)
+        return;
+    const int cj = cjg - cg.y0;
+    const int ci = x / 2;
+    const int ci1 = ci + 1 < cg.nx ? ci + 1 : ci;
+    const int cjc = cj < cg.ny ? cj : cg.ny - 1; // rows past the range are masked below
+    const int cj1 = cjc + 1 < cg.ny ? cjc + 1 : cjc;
+    const long long cp = cg.pitch, cs = cg.slab;
+    const long long o00 = ci + cp * cjc, o10 = ci1 + cp * cjc, o01 = ci + cp * cj1, o11 = ci1 + cp * cj1;
+    const R wu = 0.5 * (x % 2);
+    int yl[2];
+    bool rowok[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        yl[b] = 2 * cjg + b - fg.y0;
+        rowok[b] = yl[b] >= ylo && yl[b] < yhi;
+    }
+    const int kb = zc * ZC;
+    const int ke = kb + ZC < cg.nz ? kb + ZC : cg.nz;
+    R e0[4], e1[4];
+    {
+        const R *pl = e + cs * kb;
+        e1[0] = pl[o00], e1[1] = pl[o10], e1[2] = pl[o01], e1[3] = pl[o11];
+    }
+    for (int ck = kb; ck < ke; ++ck) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e0[i] = e1[i];
+        {
+            const R *pl = e + cs * (ck + 1 < cg.nz ? ck + 1 : ck);
+            e1[0] = pl[o00], e1[1] = pl[o10], e1[2] = pl[o01], e1[3] = pl[o11];
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int z = 2 * ck + c;
+            if (z >= fg.nz)
+                break;
+            const R wv = 0.5 * c;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (!rowok[b])
+                    continue;
+                const R ww = 0.5 * b;
+                const long long d = x + (long long)fg.pitch * yl[b] + fg.slab * z;
+                R val;
+                if (is_border(cell_class<3, MAP>(fg, x, yl[b], z))) {
+                    val = e0[0];
+                } else {
+                    const R n10 = (1.0 - wu) * (1.0 - ww) * (1.0 - wv), n11 = (1.0 - ww) * wu * (1.0 - wv),
+                            n12 = (1.0 - wu) * ww * (1.0 - wv), n13 = ww * wu * (1.0 - wv);
+                    const R n20 = (1.0 - wu) * (1.0 - ww) * wv, n21 = (1.0 - ww) * wu * wv,
+                            n22 = (1.0 - wu) * ww * wv, n23 = ww * wu * wv;
+                    val = dot4<R>(e0[0], e0[1], e0[2], e0[3], n10, n11, n12, n13) +
+                          dot4<R>(e1[0], e1[1], e1[2], e1[3], n20, n21, n22, n23);
+                }
+                out[d] = MODE == 0 ? u[d] + val * 4 : val;
+            }
+        }
+    }
 }
 
 // ---- element-wise helpers -----------------------------------------------------------------------
@@ -475,21 +815,26 @@ mgrt_status residual(const mgrt_grid *g, R *r, const R *u, const R *f, int zero_
         return MGRT_OK;
     }
     constexpr int ZC = 16;
-    dim3 grid(blocks_for(n, 256), g->dim == 3 ? blocks_for(g->nz, ZC) : 1);
-    const int nparts = (int)(grid.x * grid.y);
+    const long long nthreads = g->dim == 3 ? (long long)((g->nx + 16 / (int)sizeof(R) - 1) / (16 / (int)sizeof(R))) * (yhi - ylo) : n;
+    const unsigned nbxy = blocks_for(nthreads, 256);
+    dim3 grid(nbxy * (g->dim == 3 ? blocks_for(g->nz, ZC) : 1));
+    const int nparts = (int)grid.x;
     MGRT_REQUIRE(!norm2 || (size_t)nparts <= runtime().partials_cap, "mgrt_residual: grid too large for the fused norm");
     double *parts = runtime().partials;
 #define MGRT_LAUNCH_RES(DIM, MAP, NORM)                                                                      \
-    k_residual<R, DIM, MAP, NORM, ZC><<<grid, 256, 0, hs>>>(*g, r, u, f, zero_unwritten, parts, ylo, yhi)
+    k_residual<R, DIM, MAP, NORM, ZC><<<grid, 256, 0, hs>>>(*g, r, u, f, zero_unwritten, parts, ylo, yhi, nbxy)
+#define MGRT_LAUNCH_RES3(MAP, NORM)                                                                           \
+    k_residual3d_v<R, MAP, NORM, ZC><<<grid, 256, 0, hs>>>(*g, r, u, f, zero_unwritten, parts, ylo, yhi, nbxy)
     const bool map = g->cells != nullptr, nrm = norm2 != nullptr;
     if (g->dim == 3) {
-        if (map) { if (nrm) MGRT_LAUNCH_RES(3, true, true); else MGRT_LAUNCH_RES(3, true, false); }
-        else     { if (nrm) MGRT_LAUNCH_RES(3, false, true); else MGRT_LAUNCH_RES(3, false, false); }
+        if (map) { if (nrm) MGRT_LAUNCH_RES3(true, true); else MGRT_LAUNCH_RES3(true, false); }
+        else     { if (nrm) MGRT_LAUNCH_RES3(false, true); else MGRT_LAUNCH_RES3(false, false); }
     } else {
         if (map) { if (nrm) MGRT_LAUNCH_RES(2, true, true); else MGRT_LAUNCH_RES(2, true, false); }
         else     { if (nrm) MGRT_LAUNCH_RES(2, false, true); else MGRT_LAUNCH_RES(2, false, false); }
     }
 #undef MGRT_LAUNCH_RES
+#undef MGRT_LAUNCH_RES3
     MGRT_HIP(hipGetLastError());
     if (nrm)
         return fold<false>(nparts, norm2, hs);
@@ -528,16 +873,50 @@ mgrt_status restrict_fw(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, c
     const long long n = (long long)coarse->nx * (cyhi - cylo);
     if (n == 0)
         return MGRT_OK;
-    dim3 grid(blocks_for(n, 256), coarse->nz);
+    const unsigned nbxy = blocks_for(n, 256);
+    dim3 grid(nbxy * (unsigned)coarse->nz);
     hipStream_t hs = (hipStream_t)s;
     const bool map = fine->cells != nullptr;
     if (fine->dim == 3) {
-        if (map) k_restrict<R, 3, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi);
-        else     k_restrict<R, 3, false><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi);
+        if (map) k_restrict<R, 3, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
+        else     k_restrict<R, 3, false><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
     } else {
-        if (map) k_restrict<R, 2, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi);
-        else     k_restrict<R, 2, false><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi);
+        if (map) k_restrict<R, 2, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
+        else     k_restrict<R, 2, false><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
     }
+    MGRT_HIP(hipGetLastError());
+    return MGRT_OK;
+}
+
+template <class R>
+mgrt_status residual_restrict(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, const R *u, const R *f, int cylo,
+                              int cyhi, mgrt_stream s)
+{
+    if (mgrt_status st = require_init()) return st;
+    if (mgrt_status st = check_pair(fine, coarse, "mgrt_residual_restrict")) return st;
+    MGRT_REQUIRE(rc && u && f, "mgrt_residual_restrict: null field");
+    MGRT_REQUIRE(0 <= cylo && cylo <= cyhi && cyhi <= coarse->ny,
+                 "mgrt_residual_restrict: coarse rows [%d,%d) outside [0,%d)", cylo, cyhi, coarse->ny);
+    if (fine->dim != 3 || fine->nx % 2 == 0 || fine->gny % 2 == 0 || fine->nz % 2 == 0)
+        return fail(MGRT_E_UNSUPPORTED, "mgrt_residual_restrict: 3D grids with odd extents only");
+    if (cylo < cyhi) {
+        // the residual of fine rows 2*jg-1 .. 2*jg+1 is formed here, which reads one row further
+        const int flo = 2 * (cylo + coarse->y0) - fine->y0, fhi = 2 * (cyhi - 1 + coarse->y0) - fine->y0;
+        MGRT_REQUIRE(flo >= 0 && fhi < fine->ny, "mgrt_residual_restrict: fine slab does not hold rows %d..%d",
+                     flo + fine->y0, fhi + fine->y0);
+        MGRT_REQUIRE((flo >= 2 || flo + fine->y0 == 0) && (fhi + 2 < fine->ny || fhi + fine->y0 == fine->gny - 1),
+                     "mgrt_residual_restrict: fine slab lacks the two halo rows of the requested coarse rows");
+    } else {
+        return MGRT_OK;
+    }
+    constexpr int KC = 32;
+    const int ntx = (coarse->nx + kRRCX - 1) / kRRCX, nty = (cyhi - cylo + kRRCY - 1) / kRRCY;
+    const dim3 grid((unsigned)(ntx * nty) * blocks_for(coarse->nz, KC));
+    hipStream_t hs = (hipStream_t)s;
+    if (fine->cells)
+        k_residual_restrict3d<R, true, KC><<<grid, kRRX * kRRY, 0, hs>>>(*fine, *coarse, rc, u, f, cylo, cyhi, ntx, nty);
+    else
+        k_residual_restrict3d<R, false, KC><<<grid, kRRX * kRRY, 0, hs>>>(*fine, *coarse, rc, u, f, cylo, cyhi, ntx, nty);
     MGRT_HIP(hipGetLastError());
     return MGRT_OK;
 }
@@ -563,8 +942,13 @@ mgrt_status interp(const mgrt_grid *fine, const mgrt_grid *coarse, R *out, const
     hipStream_t hs = (hipStream_t)s;
     const bool map = fine->cells != nullptr;
     if (fine->dim == 3) {
-        if (map) k_interp<R, 3, true, MODE><<<grid, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi);
-        else     k_interp<R, 3, false, MODE><<<grid, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi);
+        constexpr int ZC = 8;
+        const int ntx = (fine->nx + 63) / 64;
+        const int cj_lo = (ylo + fine->y0) / 2, cj_hi = (yhi - 1 + fine->y0) / 2;
+        const int nty = (cj_hi - cj_lo + 1 + 3) / 4;
+        const dim3 g1((unsigned)(ntx * nty) * blocks_for(coarse->nz, ZC));
+        if (map) k_interp3d_march<R, true, MODE, ZC><<<g1, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi, ntx, nty);
+        else     k_interp3d_march<R, false, MODE, ZC><<<g1, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi, ntx, nty);
     } else {
         if (map) k_interp<R, 2, true, MODE><<<grid, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi);
         else     k_interp<R, 2, false, MODE><<<grid, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi);
@@ -700,6 +1084,9 @@ template <class R, bool MAX> mgrt_status reftree(const R *x, long long n, R *res
     extern "C" mgrt_status mgrt_restrict##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, const R *rf, \
                                             int cylo, int cyhi, mgrt_stream s)                                 \
     { return restrict_fw<R>(fine, coarse, rc, rf, cylo, cyhi, s); }                                            \
+    extern "C" mgrt_status mgrt_residual_restrict##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc,        \
+                                                     const R *u, const R *f, int cylo, int cyhi, mgrt_stream s) \
+    { return residual_restrict<R>(fine, coarse, rc, u, f, cylo, cyhi, s); }                                    \
     extern "C" mgrt_status mgrt_correct##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *out, const R *u,  \
                                            const R *e, int ylo, int yhi, mgrt_stream s)                        \
     { return interp<R, 0>(fine, coarse, out, u, e, ylo, yhi, s); }                                             \

@@ -150,6 +150,34 @@ def test_fused_sweep_matches_oracle(dev, mgo, dt, shape):
     assert torch.equal(du.cpu(), torch.from_numpy(u))  # the input is not modified
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", [(9, 11, 13), (5, 5, 5), (3, 3, 3), (33, 17, 65), (17, 131, 71), (41, 61, 59),
+                                   (7, 25, 121), (21, 9, 129)],
+                         ids=lambda s: "x".join(map(str, s[::-1])))
+def test_fused_residual_restrict_matches_oracle(dev, mgo, dt, shape):
+    """Restrict(f - A u) in one kernel against the oracle's residual followed by its restriction."""
+    import torch
+    from multigrid_amd import _lib as L
+    rng = np.random.default_rng(abs(hash((shape, dt.__name__, "rr"))) % 2**32)
+    cs = tuple((s + 1) // 2 for s in shape)
+    variants = [(mgo.box_cells(shape), None, (2,) * 6), (mgo.box_cells(shape, (2, 3, 3, 2, 2, 3)), None, (2, 3, 3, 2, 2, 3))]
+    if min(shape) >= 5:
+        c = random_cells(mgo, rng, shape)
+        variants.append((c, c, (2,) * 6))
+    for cell, dmap, faces in variants:
+        dcell = to_dev(dmap, dev) if dmap is not None else None
+        g, gc = L.grid(shape, cells=dcell, faces=faces), L.grid(cs)
+        u = rng.standard_normal(shape).astype(dt)
+        f = rng.standard_normal(shape).astype(dt)
+        r = np.zeros(shape, dt)
+        mgo.residual(cell, r, u, f)
+        ref = np.zeros(cs, dt)
+        mgo.restrict(cell, ref, r)
+        out = torch.full(cs, 99.0, dtype=to_dev(u, dev).dtype, device=dev)
+        L.residual_restrict(g, gc, out, to_dev(u, dev), to_dev(f, dev))
+        assert bits_equal(out.cpu().numpy(), ref), (shape, faces, dmap is not None)
+
+
 def test_fused_sweep_on_a_slab(dev):
     """Rows of a y-slab (odd global offset, so the colours are shifted) equal the whole-grid rows
     wherever the halo of 2*iters rows was available."""
