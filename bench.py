@@ -37,6 +37,21 @@ def make_problem(n, device):
     return f.contiguous(), sol.contiguous()
 
 
+def pmc_traffic(kernel, n):
+    """HBM bytes per launch of `kernel` at n^3 from the committed counter passes (profiles/
+    pmc_traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE and WRITE_SIZE
+    rocprofv3 runs).  None when no pass for this size is on file: counters cannot be read from
+    inside the timed process."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            for row in json.load(fh):
+                if row["kernel"] == kernel and row["n"] == n and row["dtype"] == "f32":
+                    return row["traffic_bytes"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(n_sample):
     """The oracle's C restatement (oracle/libmg_oracle.so, OpenMP) timed on this host on a bounded
     sample: one V(2,2) cycle of the same problem at n_sample^3."""
@@ -114,18 +129,20 @@ def main():
         dt = time.perf_counter() - t0
         r1 = plan.vcycle(u, f, ncycles=0, history=True)[0]
 
-        # dominant kernel: one colour pass of the smoother on the finest level, timed alone with
-        # events on the stream it runs on
+        # dominant kernel: the fused smoother sweep (two red-black iterations per launch) on the
+        # finest level, timed alone with events on the stream it runs on
         g = _lib.grid(shape)
         reps = 20
-        _lib.smooth_pass(g, u, f, 1.0, 0)
+        work = torch.empty_like(u)
+        _lib.smooth_sweep(g, work, u, f, 1.0, 2)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        for i in range(reps):
-            _lib.smooth_pass(g, u, f, 1.0, i & 1)
+        for i in range(reps // 2):
+            _lib.smooth_sweep(g, work, u, f, 1.0, 2)
+            _lib.smooth_sweep(g, u, work, f, 1.0, 2)
         e1.record(stream)
         e1.synchronize()
-        t_pass = e0.elapsed_time(e1) * 1e-3 / reps
+        t_sweep = e0.elapsed_time(e1) * 1e-3 / reps
         plan.close()
 
     if world > 1:
@@ -135,8 +152,9 @@ def main():
 
     if rank == 0:
         dof = float(n) ** 3
-        alg_bytes = 2.0 * dof * 4  # colour pass: read every u, read f and write u on the active colour
-        achieved = alg_bytes / t_pass / 1e9
+        alg_bytes = 3.0 * dof * 4  # sweep: read u, read f, write the smoothed field, once each
+        achieved = alg_bytes / t_sweep / 1e9
+        traffic = pmc_traffic("k_smooth3d_fused", n)
         # algorithmic bytes of a whole unfused V(2,2) cycle: 22 N w + 3 Nc w per level, 16 N w coarsest
         sizes, m = [], n
         while True:
@@ -156,10 +174,10 @@ def main():
                        "residual_before": r0, "residual_after_warmup_and_steps": r1},
             "vcycles_per_s": world * args.steps / dt,
             "cycle_gbs_unfused_model": cyc_bytes * args.steps / dt / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "smoother colour pass, finest level",
+            "roofline": {"bound": "hbm", "kernel": "k_smooth3d_fused, 2 red-black iterations per sweep, finest level",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_s": t_pass},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_s": t_sweep},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n)
