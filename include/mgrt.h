@@ -151,7 +151,9 @@ mgrt_status mgrt_box_cells_host(int dim, int nx, int ny, int nz, const int face[
        (auxiliary.cpp:119-173, auxiliary.h:72-82, common_kernels.cl:13-53); sqrt on the host.     \
        Dense arrays only (pitch == nx, slab == nx*ny). */                                         \
     mgrt_status mgrt_l2norm_reftree##S(const R *x, long long n, R *result, mgrt_stream s);         \
-    mgrt_status mgrt_linfnorm_reftree##S(const R *x, long long n, R *result, mgrt_stream s);
+    mgrt_status mgrt_linfnorm_reftree##S(const R *x, long long n, R *result, mgrt_stream s);        \
+    /* The same tree over the plain values: the sum that Average divides (auxiliary.h:84-94). */   \
+    mgrt_status mgrt_sum_reftree##S(const R *x, long long n, R *result, mgrt_stream s);
 
 MGRT_DECLARE_KERNELS(float, _f32)
 MGRT_DECLARE_KERNELS(double, _f64)

@@ -41,7 +41,7 @@ class PlanDesc(C.Structure):
 
 # every symbol include/mgrt.h declares; checked by the CPU test-suite against the header
 _KERNELS = ["smooth_pass", "smooth", "smooth_sweep", "residual", "restrict", "residual_restrict", "correct", "prolong", "zero_outside",
-            "diff", "sumsq", "maxabs", "l2norm_reftree", "linfnorm_reftree"]
+            "diff", "sumsq", "maxabs", "l2norm_reftree", "linfnorm_reftree", "sum_reftree"]
 _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "upload", "download",
             "stream_create", "stream_destroy", "sync", "zero", "box_cells_host",
             "plan_create", "plan_destroy", "plan_levels", "plan_level_dims", "plan_set_cells",
@@ -98,6 +98,7 @@ def load():
             "maxabs": [G, p, p, i, i, p],
             "l2norm_reftree": [p, ll, C.POINTER(r), p],
             "linfnorm_reftree": [p, ll, C.POINTER(r), p],
+            "sum_reftree": [p, ll, C.POINTER(r), p],
         }
         for name, args in ksig.items():
             f = getattr(lib, "mgrt_%s_%s" % (name, S))
@@ -223,6 +224,12 @@ def maxabs(g, x, out, ylo=0, yhi=None, stream=None):
 def l2norm_reftree(x, stream=None):
     r = (C.c_float if _suffix(x) == "f32" else C.c_double)()
     check(_fn("l2norm_reftree", x)(_p(x), x.numel(), C.byref(r), _stream(stream)))
+    return r.value
+
+
+def sum_reftree(x, stream=None):
+    r = (C.c_float if _suffix(x) == "f32" else C.c_double)()
+    check(_fn("sum_reftree", x)(_p(x), x.numel(), C.byref(r), _stream(stream)))
     return r.value
 
 

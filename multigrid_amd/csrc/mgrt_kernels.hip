@@ -1018,9 +1018,11 @@ mgrt_status norm(const mgrt_grid *g, const R *x, double *out, int ylo, int yhi, 
 }
 
 // Blocking: allocates the tree's intermediate arrays like the reference does (auxiliary.cpp:124).
-template <class R, bool MAX> mgrt_status reftree(const R *x, long long n, R *result, mgrt_stream s)
+// MODE 0: L2 norm (square, sum, sqrt); 1: L-infinity norm; 2: plain sum (Average, auxiliary.h:84-94).
+template <class R, int MODE> mgrt_status reftree(const R *x, long long n, R *result, mgrt_stream s)
 {
-    const char *who = MAX ? "mgrt_linfnorm_reftree" : "mgrt_l2norm_reftree";
+    constexpr bool MAX = MODE == 1;
+    const char *who = MODE == 1 ? "mgrt_linfnorm_reftree" : MODE == 0 ? "mgrt_l2norm_reftree" : "mgrt_sum_reftree";
     if (mgrt_status st = require_init()) return st;
     MGRT_REQUIRE(x && result && n > 0, "%s: bad argument", who);
     hipStream_t hs = (hipStream_t)s;
@@ -1030,7 +1032,7 @@ template <class R, bool MAX> mgrt_status reftree(const R *x, long long n, R *res
         // path has squared it first
         MGRT_HIP(hipMemcpyAsync(&host, x, sizeof(R), hipMemcpyDeviceToHost, hs));
         MGRT_HIP(hipStreamSynchronize(hs));
-        *result = MAX ? host : (R)sqrt((double)(host * host));
+        *result = MODE == 0 ? (R)sqrt((double)(host * host)) : host;
         return MGRT_OK;
     }
     R *buf[2] = {nullptr, nullptr};
@@ -1046,7 +1048,7 @@ template <class R, bool MAX> mgrt_status reftree(const R *x, long long n, R *res
     bool first = true;
     while (size != 1) {
         const long long newn = size / 4 > 1 ? size / 4 : 1;
-        if (first && !MAX)
+        if (first && MODE == 0)
             k_reftree_level<R, false, true><<<blocks_for(newn, 256), 256, 0, hs>>>(in, buf[which], size, newn);
         else
             k_reftree_level<R, MAX, false><<<blocks_for(newn, 256), 256, 0, hs>>>(in, buf[which], size, newn);
@@ -1064,7 +1066,7 @@ template <class R, bool MAX> mgrt_status reftree(const R *x, long long n, R *res
     (void)hipFree(buf[1]);
     if (e != hipSuccess)
         return fail((mgrt_status)e, "%s: %s", who, hipGetErrorString(e));
-    *result = MAX ? host : (R)sqrt((double)host);
+    *result = MODE == 0 ? (R)sqrt((double)host) : host;
     return MGRT_OK;
 }
 
@@ -1104,9 +1106,11 @@ template <class R, bool MAX> mgrt_status reftree(const R *x, long long n, R *res
                                           mgrt_stream s)                                                       \
     { return norm<R, true>(g, x, out, ylo, yhi, s); }                                                          \
     extern "C" mgrt_status mgrt_l2norm_reftree##S(const R *x, long long n, R *result, mgrt_stream s)           \
-    { return reftree<R, false>(x, n, result, s); }                                                             \
+    { return reftree<R, 0>(x, n, result, s); }                                                                 \
     extern "C" mgrt_status mgrt_linfnorm_reftree##S(const R *x, long long n, R *result, mgrt_stream s)         \
-    { return reftree<R, true>(x, n, result, s); }
+    { return reftree<R, 1>(x, n, result, s); }                                                                 \
+    extern "C" mgrt_status mgrt_sum_reftree##S(const R *x, long long n, R *result, mgrt_stream s)              \
+    { return reftree<R, 2>(x, n, result, s); }
 
 MGRT_DEFINE_KERNELS(float, _f32)
 MGRT_DEFINE_KERNELS(double, _f64)

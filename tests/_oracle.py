@@ -138,7 +138,21 @@ class Oracle:
     def set_celltype(self, fn):
         """fn(x, y, z, nx, ny, nz) -> cell type, or None for the all-Dirichlet box."""
         self._cb = CELLTYPE_FN(fn) if fn is not None else None
+        self._pyfn = fn
         self._set_celltype(C.cast(self._cb, C.c_void_p) if self._cb else None)
+
+    def level_cells(self, shape):
+        """The byte map of a grid under the active cell rule (set_celltype), as the cycle drivers see it."""
+        fn = getattr(self, "_pyfn", None)
+        if fn is None:
+            return self.box_cells(shape)
+        dim, nx, ny, nz = self._dims(shape)
+        cell = np.empty((nz, ny, nx), dtype=np.uint8)
+        for z in range(nz):
+            for y in range(ny):
+                for x in range(nx):
+                    cell[z, y, x] = fn(x, y, z, nx, ny, nz)
+        return cell.reshape(shape)
 
     def discretize(self, problem, shape, dtype):
         """problem 0: 3D tridimF1/tridimS1; 1: 2D sinfunc2; 2: 2D sinfunc1 -> (func, sol)"""

@@ -120,6 +120,17 @@ def test_kernels_match_oracle(dev, mgo, dt, shape):
         assert out.item() == float(np.abs(u).max())
         assert L.l2norm_reftree(du) == mgo.l2norm_tree(u)
         assert L.linfnorm_reftree(du) == mgo.linfnorm_tree(u)
+        # the sum tree of Average (auxiliary.h:84-94): groups of 4 folded left to right in R,
+        # tail elements beyond 4*(n/4) dropped at every level
+        t = u.ravel().copy()
+        while t.size > 1:
+            m = max(1, t.size // 4)
+            nxt = np.zeros(m, t.dtype)
+            for k in range(4):
+                part = t[k:4 * m:4] if t.size >= 4 else t[k:k + 1]
+                nxt[:part.size] = nxt[:part.size] + part
+            t = nxt
+        assert L.sum_reftree(du) == t[0]
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
