@@ -175,7 +175,8 @@ typedef struct mgrt_plan_desc {
     int elem_size;    /* 4 = float, 8 = double */
     int face[6];      /* box face types, used for every level without an uploaded cell map */
     int zfull;        /* 0: reference z range ceil(nz/2) in the 3D smoother; 1: all planes */
-    int use_graph;    /* replay each distinct cycle from a captured hipGraph */
+    int use_graph;    /* replay each distinct cycle from a captured hipGraph (ignored on the
+                         default stream, which cannot be captured) */
     int no_fuse;      /* 1: smooth with one launch per colour pass (the unfused schedule) */
 } mgrt_plan_desc;
 

@@ -272,6 +272,8 @@ mgrt_status mgrt_plan_create(mgrt_plan **plan, const mgrt_plan_desc *d, mgrt_str
     mgrt_plan *p = new mgrt_plan;
     p->desc = *d;
     p->stream = (hipStream_t)s;
+    if (!p->stream)
+        p->desc.use_graph = 0; // the default stream cannot be captured: launch directly
     int nx = d->nx, ny = d->ny, nz = nz0;
     for (;;) {
         mgrt_plan::Level L;

@@ -1,0 +1,81 @@
+"""One rank of a slab-decomposed V-cycle test.  Launched by tests/test_dist.py through
+torch.distributed.run; exits non-zero when this rank's rows differ from the whole-grid oracle.
+
+  dist_worker.py BACKEND NZ NY NX DTYPE OMEGA A1 A2 V NCYCLES ZFULL CROSSOVER
+
+BACKEND cpu: gloo, CPU tensors, oracle-backed kernels.  BACKEND gpu: gloo with host staging, every
+rank on cuda:0, the HIP kernels (for a one-GPU box)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def main():
+    backend = sys.argv[1]
+    nz, ny, nx = (int(a) for a in sys.argv[2:5])
+    dt = np.float32 if sys.argv[5] == "f32" else np.float64
+    omega, a1, a2, v, ncycles, zfull, crossover = (float(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8]),
+                                                   int(sys.argv[9]), int(sys.argv[10]), bool(int(sys.argv[11])),
+                                                   int(sys.argv[12]))
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import _oracle
+    from multigrid_amd import dist as slab
+    o = _oracle.load("mgo")
+    o.set_num_threads(1)
+    shape = (nz, ny, nx)
+    rng = np.random.default_rng(1234)
+    f = rng.standard_normal(shape).astype(dt)
+    u0 = rng.standard_normal(shape).astype(dt)
+    ref = u0.copy()
+    hist_ref = []
+    cell = o.box_cells(shape)
+
+    def norm(x):
+        r = np.zeros_like(x)
+        o.residual(cell, r, x, f)
+        return o.l2norm_exact(r)
+    hist_ref.append(norm(ref))
+    for _ in range(ncycles):
+        o.iterate(ref, f, dt(omega), a1, a2, v, zfull)
+        hist_ref.append(norm(ref))
+
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    if backend == "cpu":
+        from _slab_backend import OracleKernels
+        kernels, device = OracleKernels(), None
+    else:
+        from multigrid_amd import _lib as kernels
+        torch.cuda.set_device(0)
+        kernels.init(0)
+        device = torch.device("cuda", 0)
+    cyc = slab.SlabCycle(shape, tdt, kernels=kernels, device=device, zfull=zfull, crossover=crossover)
+    assert cyc.ndist >= 1, "this case does not split: pick a larger grid or a smaller crossover"
+    to = (lambda a: torch.from_numpy(a.copy())) if device is None else (lambda a: torch.from_numpy(a.copy()).to(device))
+    ul, fl = cyc.scatter(to(u0)), cyc.scatter(to(f))
+    hist = cyc.vcycle(ul, fl, omega, a1, a2, v, ncycles, history=True)
+    lo, hi, a, b = cyc.local_rows()
+    mine = cyc.owned(ul).cpu().numpy()
+    want = ref[:, a:b, :]
+    ok = np.array_equal(mine.view(np.uint8), want.view(np.uint8))
+    hok = all(abs(h - r) <= 1e-9 * max(r, 1e-300) for h, r in zip(hist, hist_ref)) and len(hist) == len(hist_ref)
+    if not ok or not hok:
+        bad = np.argwhere(mine != want)
+        print("rank %d/%d rows [%d,%d) ndist %d: mismatch at %d cells, first %s; hist %s vs %s"
+              % (rank, world, a, b, cyc.ndist, len(bad), bad[:3].tolist(), hist, hist_ref), flush=True)
+    flag = torch.tensor([0 if ok and hok else 1])
+    dist.all_reduce(flag)
+    cyc.close()
+    dist.destroy_process_group()
+    sys.exit(1 if flag.item() else 0)
+
+
+if __name__ == "__main__":
+    main()
