@@ -7,8 +7,9 @@ A step is one V(2,2) cycle (omega = 1, pre/post smoothing 2+2, one coarse solve 
 over every z plane) on fields already resident in HBM.  Prints ONE JSON line:
 value = finest-grid points x cycles / second over all GPUs.
 
-For N > 1 the driver launches one process per GPU with torch.distributed.run; each rank then runs
-its own 513^3 problem (independent replicas, weak scaling, no data-path collective).
+For N > 1 the driver launches one process per GPU with torch.distributed.run; the 513^3 grid is cut
+into N slabs along y (multigrid_amd/dist.py): halo exchange over RCCL before each fused sweep, the
+levels of at most 65^3 points solved whole on every rank.  Total work is fixed: strong scaling.
 """
 import argparse
 import json
@@ -37,7 +38,7 @@ def make_problem(n, device):
     return f.contiguous(), sol.contiguous()
 
 
-def pmc_traffic(kernel, n):
+def pmc_traffic(kernel, n, template=""):
     """HBM bytes per launch of `kernel` at n^3 from the committed counter passes (profiles/
     pmc_traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE and WRITE_SIZE
     rocprofv3 runs).  None when no pass for this size is on file: counters cannot be read from
@@ -45,7 +46,8 @@ def pmc_traffic(kernel, n):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             for row in json.load(fh):
-                if row["kernel"] == kernel and row["n"] == n and row["dtype"] == "f32":
+                if row["kernel"] == kernel and row["n"] == n and row["dtype"] == "f32" and \
+                        row["template"].replace(" ", "").startswith(template):
                     return row["traffic_bytes"]
     except (OSError, ValueError, KeyError):
         pass
@@ -89,6 +91,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-n", type=int, default=257)
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on a one-GPU box: every rank on cuda:0, gloo with host staging; checks that the "
+                         "path runs, the number is not a measurement")
+    ap.add_argument("--crossover", type=int, default=65 ** 3,
+                    help="N > 1: levels with at most this many points are solved whole on every rank")
     args = ap.parse_args()
 
     import torch
@@ -99,10 +106,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if args.rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     _lib.init(local)
 
     n = args.n
@@ -115,19 +127,44 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.all_reduce(sync)
+            dist.all_reduce(sync.cpu() if args.rehearse else sync)
             torch.cuda.synchronize()
 
-    with torch.cuda.stream(stream):
-        plan = _lib.Plan(shape, torch.float32, zfull=True, use_graph=not args.no_graph)
-        r0 = plan.vcycle(u, f, ncycles=0, history=True)[0]
-        plan.vcycle(u, f, 1.0, 2, 2, 1, args.warmup)
+    t_sweep = None
+    if world > 1:
+        from multigrid_amd import dist as slab
+        cyc = slab.SlabCycle(shape, torch.float32, device=dev, zfull=True, crossover=args.crossover,
+                             use_graph=not args.no_graph)
+        fl, ul = cyc.scatter(f), cyc.scatter(u)
+        del f, u
+        r0 = cyc.residual_norm(ul, fl)
+        cyc.vcycle(ul, fl, 1.0, 2, 2, 1, args.warmup)
         barrier()
         t0 = time.perf_counter()
-        plan.vcycle(u, f, 1.0, 2, 2, 1, args.steps)
+        cyc.vcycle(ul, fl, 1.0, 2, 2, 1, args.steps)
         barrier()
         dt = time.perf_counter() - t0
-        r1 = plan.vcycle(u, f, ncycles=0, history=True)[0]
+        r1 = cyc.residual_norm(ul, fl)
+        layout = {"slab_rows": [b - a for a, b in zip(cyc.bounds, cyc.bounds[1:])], "halo_rows": slab.HALO,
+                  "distributed_levels": cyc.ndist, "replicated_from": "x".join(map(str, cyc.coarse_shape))}
+        cyc.close()
+
+    with torch.cuda.stream(stream):
+        if world == 1:
+            plan = _lib.Plan(shape, torch.float32, zfull=True, use_graph=not args.no_graph)
+            r0 = plan.vcycle(u, f, ncycles=0, history=True)[0]
+            plan.vcycle(u, f, 1.0, 2, 2, 1, args.warmup)
+            barrier()
+            t0 = time.perf_counter()
+            plan.vcycle(u, f, 1.0, 2, 2, 1, args.steps)
+            barrier()
+            dt = time.perf_counter() - t0
+            r1 = plan.vcycle(u, f, ncycles=0, history=True)[0]
+            plan.close()
+            layout = None
+        else:
+            f, _ = make_problem(n, dev)
+            u = torch.zeros_like(f)
 
         # dominant kernel: the fused smoother sweep (two red-black iterations per launch) on the
         # finest level, timed alone with events on the stream it runs on
@@ -143,10 +180,9 @@ def main():
         e1.record(stream)
         e1.synchronize()
         t_sweep = e0.elapsed_time(e1) * 1e-3 / reps
-        plan.close()
 
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if args.rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
@@ -154,7 +190,7 @@ def main():
         dof = float(n) ** 3
         alg_bytes = 3.0 * dof * 4  # sweep: read u, read f, write the smoothed field, once each
         achieved = alg_bytes / t_sweep / 1e9
-        traffic = pmc_traffic("k_smooth3d_fused", n)
+        traffic = pmc_traffic("k_smooth3d_fused", n, "float,2,")  # <R, ITERS = 2, ...>: the variant timed here
         # algorithmic bytes of a whole unfused V(2,2) cycle: 22 N w + 3 Nc w per level, 16 N w coarsest
         sizes, m = [], n
         while True:
@@ -164,15 +200,17 @@ def main():
             m = (m + 1) // 2
         cyc_bytes = sum((22 * s ** 3 + 3 * ((s + 1) // 2) ** 3) * 4 for s in sizes[:-1]) + 16 * sizes[-1] ** 3 * 4
         out = {
-            "metric": "3D 513^3 V-cycle DOF/s", "value": world * dof * args.steps / dt, "unit": "DOF/s",
+            "metric": "3D 513^3 V-cycle DOF/s", "value": dof * args.steps / dt, "unit": "DOF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            **({"rehearsal": "all ranks on one GPU over gloo: not a measurement"} if args.rehearse else {}),
             "config": {"workload": "3D Poisson %d^3 Dirichlet box, V(2,2), omega=1, smoother over all z planes" % n,
                        "levels": len(sizes), "graph": not args.no_graph,
-                       "parallelism": "single GPU" if world == 1 else "%d independent replicas" % world,
+                       "parallelism": "single GPU" if world == 1 else "%d y-slabs, RCCL halo exchange" % world,
+                       "layout": layout,
                        "residual_before": r0, "residual_after_warmup_and_steps": r1},
-            "vcycles_per_s": world * args.steps / dt,
+            "vcycles_per_s": args.steps / dt,
             "cycle_gbs_unfused_model": cyc_bytes * args.steps / dt / 1e9,
             "roofline": {"bound": "hbm", "kernel": "k_smooth3d_fused, 2 red-black iterations per sweep, finest level",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
