@@ -256,10 +256,10 @@ template <class R, int VX> __device__ __forceinline__ void load_vec(R (&d)[VX], 
     }
 }
 
-template <class R, bool MAP, bool NORM, int ZC>
+template <class R, bool MAP, bool NORM>
 __global__ __launch_bounds__(256) void k_residual3d_v(mgrt_grid g, R *r, const R *__restrict__ u,
                                                       const R *__restrict__ f, int zero_unwritten,
-                                                      double *partials, int ylo, int yhi, unsigned nbxy)
+                                                      double *partials, int ylo, int yhi, unsigned nbxy, int ZC)
 {
     constexpr int VX = 16 / (int)sizeof(R);
     const unsigned bid = (unsigned)xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
@@ -677,6 +677,110 @@ __global__ __launch_bounds__(256) void k_interp3d_march(mgrt_grid fg, mgrt_grid 
     }
 }
 
+// The same march with 16 bytes per lane on the fine side: a thread owns VX consecutive fine x
+// (4 floats / 2 doubles, starting at an even x) of the fine row pair (2j, 2j+1) and keeps the
+// VX/2+1 coarse values per coarse row and plane that they interpolate from.  Per 4*VX fine points
+// and coarse plane: 2*(VX/2+1) coarse loads, 4 wide loads of u, 4 wide stores.  `zchunk` coarse
+// planes per thread.  Same expressions, same operand order as k_interp.
+template <class R, bool MAP, int MODE>
+__global__ __launch_bounds__(256) void k_interp3d_v(mgrt_grid fg, mgrt_grid cg, R *out, const R *u,
+                                                    const R *__restrict__ e, int ylo, int yhi, int ncrows,
+                                                    unsigned nbxy, int zchunk)
+{
+    constexpr int VX = 16 / (int)sizeof(R), NC = VX / 2 + 1;
+    const unsigned bid = (unsigned)xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const unsigned bxy = bid % nbxy, zc = bid / nbxy;
+    const unsigned nvx = ((unsigned)fg.nx + VX - 1) / VX;
+    const unsigned idx = bxy * 256u + threadIdx.x;
+    if (idx >= nvx * (unsigned)ncrows)
+        return;
+    const int x0 = (int)(idx % nvx) * VX;
+    const int nval = fg.nx - x0 < VX ? fg.nx - x0 : VX;
+    // global coarse row handled by this thread; its fine rows are 2*cjg and 2*cjg+1
+    const int cjg = (ylo + fg.y0) / 2 + (int)(idx / nvx);
+    const int cj = cjg - cg.y0;
+    const int cjc = cj < cg.ny ? cj : cg.ny - 1; // rows past the range are masked below
+    const int cj1 = cjc + 1 < cg.ny ? cjc + 1 : cjc;
+    const long long cp = cg.pitch, cs = cg.slab;
+    long long o0[NC], o1[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int ci = x0 / 2 + k < cg.nx ? x0 / 2 + k : cg.nx - 1;
+        o0[k] = ci + cp * cjc;
+        o1[k] = ci + cp * cj1;
+    }
+    int yl[2];
+    bool rowok[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        yl[b] = 2 * cjg + b - fg.y0;
+        rowok[b] = yl[b] >= ylo && yl[b] < yhi;
+    }
+    const int kb = (int)zc * zchunk;
+    const int ke = kb + zchunk < cg.nz ? kb + zchunk : cg.nz;
+    // [plane][row][k]
+    R lo[2][NC], hi[2][NC];
+    {
+        const R *pl = e + cs * kb;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) hi[0][k] = pl[o0[k]], hi[1][k] = pl[o1[k]];
+    }
+    for (int ck = kb; ck < ke; ++ck) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) lo[0][k] = hi[0][k], lo[1][k] = hi[1][k];
+        {
+            const R *pl = e + cs * (ck + 1 < cg.nz ? ck + 1 : ck);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) hi[0][k] = pl[o0[k]], hi[1][k] = pl[o1[k]];
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int z = 2 * ck + c;
+            if (z >= fg.nz)
+                break;
+            const R wv = 0.5 * c;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (!rowok[b])
+                    continue;
+                const R ww = 0.5 * b;
+                const long long d = x0 + (long long)fg.pitch * yl[b] + fg.slab * z;
+                R uv[VX], res[VX];
+                if (MODE == 0)
+                    load_vec<R, VX>(uv, u + d, nval);
+#pragma unroll
+                for (int el = 0; el < VX; ++el) {
+                    const R wu = 0.5 * (el % 2);
+                    const int k = el / 2;
+                    R val;
+                    if (el >= nval || is_border(cell_class<3, MAP>(fg, x0 + el, yl[b], z))) {
+                        val = lo[0][k];
+                    } else {
+                        const R n10 = (1.0 - wu) * (1.0 - ww) * (1.0 - wv), n11 = (1.0 - ww) * wu * (1.0 - wv),
+                                n12 = (1.0 - wu) * ww * (1.0 - wv), n13 = ww * wu * (1.0 - wv);
+                        const R n20 = (1.0 - wu) * (1.0 - ww) * wv, n21 = (1.0 - ww) * wu * wv,
+                                n22 = (1.0 - wu) * ww * wv, n23 = ww * wu * wv;
+                        val = dot4<R>(lo[0][k], lo[0][k + 1], lo[1][k], lo[1][k + 1], n10, n11, n12, n13) +
+                              dot4<R>(hi[0][k], hi[0][k + 1], hi[1][k], hi[1][k + 1], n20, n21, n22, n23);
+                    }
+                    res[el] = MODE == 0 ? uv[el] + val * 4 : val;
+                }
+                if (nval == VX) {
+                    VecU<R, VX> t;
+#pragma unroll
+                    for (int el = 0; el < VX; ++el) t.v[el] = res[el];
+                    *reinterpret_cast<VecU<R, VX> *>(out + d) = t;
+                } else {
+#pragma unroll
+                    for (int el = 0; el < VX; ++el)
+                        if (el < nval)
+                            out[d + el] = res[el];
+                }
+            }
+        }
+    }
+}
+
 // ---- element-wise helpers -----------------------------------------------------------------------
 template <class R, int DIM, bool MAP> __global__ __launch_bounds__(256) void k_zero_outside(mgrt_grid g, R *u)
 {
@@ -744,6 +848,16 @@ __global__ __launch_bounds__(256) void k_reftree_level(const R *in, R *out, long
 }
 
 inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// Planes per thread for the z-marching streaming kernels: `most` on large grids (register reuse
+// along z), fewer on small ones so that the launch still has a few blocks per CU.
+inline int z_chunk(unsigned blocks_xy, int nz, int most)
+{
+    int zc = most;
+    while (zc > 1 && (unsigned long long)blocks_xy * ((nz + zc - 1) / zc) < 1024)
+        zc /= 2;
+    return zc;
+}
 
 // ---- launchers ---------------------------------------------------------------------------------
 template <class R>
@@ -817,14 +931,15 @@ mgrt_status residual(const mgrt_grid *g, R *r, const R *u, const R *f, int zero_
     constexpr int ZC = 16;
     const long long nthreads = g->dim == 3 ? (long long)((g->nx + 16 / (int)sizeof(R) - 1) / (16 / (int)sizeof(R))) * (yhi - ylo) : n;
     const unsigned nbxy = blocks_for(nthreads, 256);
-    dim3 grid(nbxy * (g->dim == 3 ? blocks_for(g->nz, ZC) : 1));
+    const int zc3 = g->dim == 3 ? z_chunk(nbxy, g->nz, ZC) : 1;
+    dim3 grid(nbxy * (g->dim == 3 ? blocks_for(g->nz, zc3) : 1));
     const int nparts = (int)grid.x;
     MGRT_REQUIRE(!norm2 || (size_t)nparts <= runtime().partials_cap, "mgrt_residual: grid too large for the fused norm");
     double *parts = runtime().partials;
 #define MGRT_LAUNCH_RES(DIM, MAP, NORM)                                                                      \
     k_residual<R, DIM, MAP, NORM, ZC><<<grid, 256, 0, hs>>>(*g, r, u, f, zero_unwritten, parts, ylo, yhi, nbxy)
 #define MGRT_LAUNCH_RES3(MAP, NORM)                                                                           \
-    k_residual3d_v<R, MAP, NORM, ZC><<<grid, 256, 0, hs>>>(*g, r, u, f, zero_unwritten, parts, ylo, yhi, nbxy)
+    k_residual3d_v<R, MAP, NORM><<<grid, 256, 0, hs>>>(*g, r, u, f, zero_unwritten, parts, ylo, yhi, nbxy, zc3)
     const bool map = g->cells != nullptr, nrm = norm2 != nullptr;
     if (g->dim == 3) {
         if (map) { if (nrm) MGRT_LAUNCH_RES3(true, true); else MGRT_LAUNCH_RES3(true, false); }
@@ -942,13 +1057,14 @@ mgrt_status interp(const mgrt_grid *fine, const mgrt_grid *coarse, R *out, const
     hipStream_t hs = (hipStream_t)s;
     const bool map = fine->cells != nullptr;
     if (fine->dim == 3) {
-        constexpr int ZC = 8;
-        const int ntx = (fine->nx + 63) / 64;
+        constexpr int VX = 16 / (int)sizeof(R);
         const int cj_lo = (ylo + fine->y0) / 2, cj_hi = (yhi - 1 + fine->y0) / 2;
-        const int nty = (cj_hi - cj_lo + 1 + 3) / 4;
-        const dim3 g1((unsigned)(ntx * nty) * blocks_for(coarse->nz, ZC));
-        if (map) k_interp3d_march<R, true, MODE, ZC><<<g1, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi, ntx, nty);
-        else     k_interp3d_march<R, false, MODE, ZC><<<g1, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi, ntx, nty);
+        const int ncrows = cj_hi - cj_lo + 1;
+        const unsigned nbxy = blocks_for((long long)((fine->nx + VX - 1) / VX) * ncrows, 256);
+        const int zchunk = z_chunk(nbxy, coarse->nz, 8);
+        const dim3 g1(nbxy * blocks_for(coarse->nz, zchunk));
+        if (map) k_interp3d_v<R, true, MODE><<<g1, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi, ncrows, nbxy, zchunk);
+        else     k_interp3d_v<R, false, MODE><<<g1, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi, ncrows, nbxy, zchunk);
     } else {
         if (map) k_interp<R, 2, true, MODE><<<grid, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi);
         else     k_interp<R, 2, false, MODE><<<grid, 256, 0, hs>>>(*fine, *coarse, out, u, e, ylo, yhi);
