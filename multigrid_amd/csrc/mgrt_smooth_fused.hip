@@ -217,7 +217,11 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                                               (xp + xm + yp + ym + C[c][PH(2 * k - 2)][j] + C[c][PH(2 * k)][j] - fv);
                                 // mg_1.cl:69; for omega == 1 the double expression reduces exactly
                                 // to val + 0*own evaluated in R
-                                const R gs = OMEGA1 ? val + (R)0 * own : (R)(val * omega + (1.0 - omega) * own);
+                                R gs = OMEGA1 ? val + (R)0 * own : (R)(val * omega + (1.0 - omega) * own);
+                                // Keep the update unconditional: left alone, the compiler sinks it
+                                // under a branch on take_gs, and the exec-mask blocks that result
+                                // serialise the independent updates of a phase and their LDS reads.
+                                asm("" : "+v"(gs));
                                 const bool take_gs = FAST ? interior[c][j] : (interior[c][j] && zin);
                                 const bool take_f = FAST ? latfix[c][j] : (interior[c][j] ? zdir : latdir[c][j]);
                                 C[c][PH(2 * k - 1)][j] = take_gs ? gs : (take_f ? fv : own);

@@ -82,10 +82,10 @@ def main():
         if ";;#ASMEND" in line:
             in_asm = False
             continue
-        if re.match(r"^\.LBB\d+_\d+:", line):
+        if re.match(r"^(\.LBB\d+_\d+:|; %bb\.\d+:)", line):
             # block labels carry the loop annotation on this or the next comment line
             depth2_here = "Depth=2" in line
-            if not depth2_here and depth2 and "Depth=1" in line:
+            if not depth2_here and depth2:  # a block of the enclosing loop, or outside every loop
                 flush()
                 depth2 = False
             if depth2_here:
