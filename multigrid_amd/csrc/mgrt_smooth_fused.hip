@@ -6,26 +6,29 @@
 // pass each (x,y) column is a recurrence in ascending z, and the four in-plane neighbours of a
 // point always have the other colour.  Hence at plane z the first colour needs only the other
 // colour's previous values of plane z, its own new value at z-1 and its own old value at z+1; the
-// second colour needs the first colour's new values of plane z.  Both passes of an iteration can
-// therefore be applied plane by plane in one march, and iteration k+1 can follow iteration k two
-// planes behind.  Every point is still computed by exactly the reference's expression from exactly
-// the values the serial NDRange schedule would feed it, so the result is identical bit for bit to
-// 2*iters launches of the single-colour kernel.
+// second colour needs the first colour's new values of plane z.  All passes can therefore be
+// applied plane by plane in one march in which every colour pass runs one plane behind the pass
+// before it: in a time step, pass number d (d = 1 .. 2*iters; colour (d-1)%2 of iteration
+// (d+1)/2) updates the plane d below the one just loaded.  The passes of one step touch different
+// planes and colours and do not depend on each other.  Every point is still computed by exactly
+// the reference's expression from exactly the values the serial NDRange schedule would feed it, so
+// the result is identical bit for bit to 2*iters launches of the single-colour kernel.
 //
 // Shape.  A block of NW wavefronts owns a tile of 64 x (NW*SR) columns including a halo of
 // H = 2*iters columns on every side (each colour update consumes one ring of halo).  A wavefront
 // owns a strip of SR consecutive rows, one lane per x; a lane keeps its SR columns in registers
 // for all planes in flight:
 //   C[c][d][j]  value of the colour-c point of row pair j (rows 2j, 2j+1) at ring depth d, where
-//               depth d is plane (t+1)-d at time step t: d=0 is the raw plane just loaded,
-//               d=2k-1 the plane iteration k updates, d=2k the plane below it (its z-1 carry),
-//               d=2*iters the plane that has just been finished and stored;
-//   F[c][d][j]  the right-hand side of the same points, d < 2*iters;
-//   prefetch registers for PF further planes of `in` and `f` (the HBM latency cover).
+//               depth d is plane i-d when plane i has just been loaded: d=0 is the raw plane,
+//               d = 1 .. 2*iters the plane pass d updates, d+1 its z-1 carry, and d=2*iters the
+//               plane that is finished and stored at the end of the step;
+//   F[c][d][j]  the right-hand side of the same points;
+//   prefetch registers for PD further planes of `in` and `f` (the HBM latency cover).
 // x neighbours come from the adjacent lanes by DPP wave shifts (no memory), y neighbours inside the
 // strip are the lane's own registers, and only the strip's first and last row are exchanged with
-// the neighbouring wavefronts through LDS, once per colour phase (one barrier each).
-// Storing by colour instead of by row makes every lane update a point in every phase: which of the
+// the neighbouring wavefronts through LDS: once per time step for all passes together (one
+// barrier per step, LDS double-buffered by step parity).
+// Storing by colour instead of by row makes every lane update a point in every pass: which of the
 // two rows of a pair holds the lane's colour-c point depends on the lane's parity only.
 #include "mgrt_internal.h"
 #include "mgrt_device.h"
@@ -38,21 +41,22 @@ namespace {
 
 constexpr int kWave = 64;
 
-template <class R, int ITERS, int SR, int NW, int PFM, bool OMEGA1>
+template <class R, int ITERS, int SR, int NW, int PD, bool OMEGA1>
 __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const R *__restrict__ in,
                                                               R *__restrict__ out, const R *__restrict__ f,
                                                               R omega, int zcount, int ntx)
 {
     static_assert(SR % 2 == 0, "rows are handled in pairs");
-    constexpr int H = 2 * ITERS, J = SR / 2, ND = 2 * ITERS + 1;
-    // The plane rings (period ND) and the prefetch ring (period PF) are addressed with indices that
-    // are compile-time constants inside a time loop unrolled PF times, PF a multiple of ND: plane i
-    // lives in ring slot i % ND and prefetch slot i % PF, nothing is ever shifted.
-    constexpr int PF = PFM * ND;
-    constexpr int kYounger = SR + (PF - 1) * 3 * SR; // see wait_slot
+    constexpr int H = 2 * ITERS, J = SR / 2, NP = 2 * ITERS, ND = NP + 2;
+    // The plane rings (period ND) and the prefetch ring (period PD) are addressed with indices that
+    // are compile-time constants inside a time loop unrolled UN times, UN a multiple of both: plane
+    // i lives in ring slot i % ND and prefetch slot i % PD, nothing is ever shifted.
+    static_assert(ND % PD == 0 || PD % ND == 0, "prefetch depth and ring depth must divide the unrolled loop");
+    constexpr int UN = ND > PD ? ND : PD;
+    constexpr int kYounger = SR + (PD - 1) * 3 * SR; // see wait_slot
     static_assert(kYounger < 64, "too many vector-memory operations in flight for a counted wait");
     constexpr int OX = kWave - 2 * H, OY = NW * SR - 2 * H;
-    __shared__ R bnd[2][ITERS][NW][2][kWave];
+    __shared__ R bnd[2][NP][NW][2][kWave];
 
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
     // Blocks are dealt to the 8 XCDs round-robin (block b and b+8 share an L2).  Give every XCD a
@@ -115,9 +119,9 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
 
     const long long slab = g.slab;
     const int zlast = g.nz - 1;
-    R pu[PF][SR], pf[PF][SR];
+    R pu[PD][SR], pf[PD][SR];
 #pragma unroll
-    for (int k = 0; k < PF; ++k) {
+    for (int k = 0; k < PD; ++k) {
         const long long zo = slab * (k < zlast ? k : zlast);
         const desc_t ru = plane_desc(in + zo, plane_bytes), rf = plane_desc(f + zo, plane_bytes);
 #pragma unroll
@@ -128,37 +132,38 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
     }
     auto drain0 = [&]() {
 #pragma unroll
-        for (int k = 0; k < PF; ++k)
+        for (int k = 0; k < PD; ++k)
             wait_slot<0>(pu[k], pf[k]);
     };
     drain0(); // the loop below starts from landed registers (see `drain`)
 
-    const int nsteps = g.nz + 2 * ITERS - 1; // planes entering the ring: 0 .. nz+2*ITERS-2
+    const int nsteps = g.nz + NP; // planes entering the ring: 0 .. nz+NP-1
     const int zlim = zcount < g.nz ? zcount : g.nz;
     const int wu = w > 0 ? w - 1 : 0, wd = w + 1 < NW ? w + 1 : NW - 1;
-    // One group of PF consecutive time steps, unrolled so that every ring index is a constant.
+    // One group of UN consecutive time steps, unrolled so that every ring index is a constant.
     // FAST groups are those whose steps all work on planes strictly between the z faces and below
     // zlim, prefetch planes that exist, and store a plane: no per-step conditions are left and the
     // class of a point is a per-lane constant.
     auto group = [&](auto fast_tag, const int i0) {
         constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int i = i0 + u; // plane entering the ring; i0 is a multiple of ND
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + u; // plane entering the ring; i0 is a multiple of UN
             if (FAST || i < nsteps) {
 #define PH(d) ((((u) - (d)) % ND + ND) % ND) /* ring slot of depth d, i.e. of plane i - d */
+                const int ps = u % PD; // prefetch slot of plane i (a constant once the loop is unrolled)
                 // ---- plane i: prefetch registers -> ring slot -----------------------------------
                 // In a fast group every step issues 2*SR loads then SR stores, so the slot's loads
-                // have SR stores and PF-1 whole steps behind them; elsewhere steps may skip their
+                // have SR stores and PD-1 whole steps behind them; elsewhere steps may skip their
                 // stores, so wait for everything.
                 if (FAST)
-                    wait_slot<kYounger>(pu[u], pf[u]);
+                    wait_slot<kYounger>(pu[ps], pf[ps]);
                 else
-                    wait_slot<0>(pu[u], pf[u]);
+                    wait_slot<0>(pu[ps], pf[ps]);
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
-                    const R a0 = pu[u][2 * j], a1 = pu[u][2 * j + 1];
-                    const R b0 = pf[u][2 * j], b1 = pf[u][2 * j + 1];
+                    const R a0 = pu[ps][2 * j], a1 = pu[ps][2 * j + 1];
+                    const R b0 = pf[ps][2 * j], b1 = pf[ps][2 * j + 1];
                     C[0][PH(0)][j] = s0 ? a1 : a0;
                     C[1][PH(0)][j] = s0 ? a0 : a1;
                     F[0][PH(0)][j] = s0 ? b1 : b0;
@@ -169,74 +174,71 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                     // ahead of the wait.
                     asm volatile("" : "+v"(C[0][PH(0)][j]), "+v"(C[1][PH(0)][j]), "+v"(F[0][PH(0)][j]), "+v"(F[1][PH(0)][j]));
                 }
-                { // plane i + PF -> prefetch slot u
-                    const int zn = i + PF;
+                { // plane i + PD -> prefetch slot ps
+                    const int zn = i + PD;
                     const long long zo = slab * (FAST || zn < zlast ? zn : zlast);
                     const desc_t ru = plane_desc(in + zo, plane_bytes), rf = plane_desc(f + zo, plane_bytes);
 #pragma unroll
                     for (int r = 0; r < SR; ++r) {
-                        buf_load_hidden(pu[u][r], ru, off[r]);
-                        buf_load_hidden(pf[u][r], rf, off[r]);
+                        buf_load_hidden(pu[ps][r], ru, off[r]);
+                        buf_load_hidden(pf[ps][r], rf, off[r]);
                     }
                 }
-                const int t = i - 1;
-                // ---- two colour phases; iteration k works on plane t - 2(k-1), depth 2k-1 ------
+                // ---- publish, for every pass, the strip's first and last row of the colour it
+                // reads.  Wherever a neighbouring strip needs the first (last) row, that row holds
+                // that colour.  None of these values changes during the step.
+                const int par = u & 1;
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
+                for (int d = 1; d <= NP; ++d) {
+                    const int oc = ((d - 1) & 1) ^ 1;
+                    bnd[par][d - 1][w][0][lane] = C[oc][PH(d)][0];
+                    bnd[par][d - 1][w][1][lane] = C[oc][PH(d)][J - 1];
+                }
+                __syncthreads();
+                // ---- the passes: pass d = colour (d-1)%2 of iteration (d+1)/2 on plane i - d ----
+#pragma unroll
+                for (int d = 1; d <= NP; ++d) {
+                    const int c = (d - 1) & 1;
                     const bool sc = (s0 ^ c) != 0; // odd row of the pair holds the colour-c point
-                    // Publish the strip's first and last row of the planes being updated.  Only the
-                    // other colour is read by this phase, and wherever a neighbouring strip needs
-                    // the first (last) row, that row holds that colour.
+                    const int z = i - d;
+                    if (FAST || (z >= 0 && z < zlim)) {
+                        const R up = bnd[par][d - 1][wu][1][lane];
+                        const R dn = bnd[par][d - 1][wd][0][lane];
+                        const int zcls = z == 0 ? g.face[4] : (z == zlast ? g.face[5] : MGRT_CELL_INNER);
+                        const bool zin = zcls == MGRT_CELL_INNER, zdir = zcls == MGRT_CELL_DIRICHLET;
 #pragma unroll
-                    for (int k = 1; k <= ITERS; ++k) {
-                        bnd[c][k - 1][w][0][lane] = C[c ^ 1][PH(2 * k - 1)][0];
-                        bnd[c][k - 1][w][1][lane] = C[c ^ 1][PH(2 * k - 1)][J - 1];
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int k = 1; k <= ITERS; ++k) {
-                        const int z = t - 2 * (k - 1);
-                        if (FAST || (z >= 0 && z < zlim)) {
-                            const R up = bnd[c][k - 1][wu][1][lane];
-                            const R dn = bnd[c][k - 1][wd][0][lane];
-                            const int zcls = z == 0 ? g.face[4] : (z == zlast ? g.face[5] : MGRT_CELL_INNER);
-                            const bool zin = zcls == MGRT_CELL_INNER, zdir = zcls == MGRT_CELL_DIRICHLET;
-#pragma unroll
-                            for (int j = 0; j < J; ++j) {
-                                const R o = C[c ^ 1][PH(2 * k - 1)][j]; // other colour, same pair
-                                const R xm = from_lower_lane(o), xp = from_upper_lane(o);
-                                const R below = j > 0 ? C[c ^ 1][PH(2 * k - 1)][j > 0 ? j - 1 : 0] : up;
-                                const R above = j + 1 < J ? C[c ^ 1][PH(2 * k - 1)][j + 1 < J ? j + 1 : 0] : dn;
-                                const R yp = sc ? above : o; // u[y+1]
-                                const R ym = sc ? o : below; // u[y-1]
-                                const R own = C[c][PH(2 * k - 1)][j];
-                                const R fv = F[c][PH(2 * k - 1)][j];
-                                // mg_1.cl:35-42: neighbours summed in R in this order, times the
-                                // double literal 1.0/6.0, rounded to R
-                                const R val = (1.0 / 6.0) *
-                                              (xp + xm + yp + ym + C[c][PH(2 * k - 2)][j] + C[c][PH(2 * k)][j] - fv);
-                                // mg_1.cl:69; for omega == 1 the double expression reduces exactly
-                                // to val + 0*own evaluated in R
-                                R gs = OMEGA1 ? val + (R)0 * own : (R)(val * omega + (1.0 - omega) * own);
-                                // Keep the update unconditional: left alone, the compiler sinks it
-                                // under a branch on take_gs, and the exec-mask blocks that result
-                                // serialise the independent updates of a phase and their LDS reads.
-                                asm("" : "+v"(gs));
-                                const bool take_gs = FAST ? interior[c][j] : (interior[c][j] && zin);
-                                const bool take_f = FAST ? latfix[c][j] : (interior[c][j] ? zdir : latdir[c][j]);
-                                C[c][PH(2 * k - 1)][j] = take_gs ? gs : (take_f ? fv : own);
-                            }
+                        for (int j = 0; j < J; ++j) {
+                            const R o = C[c ^ 1][PH(d)][j]; // other colour, same pair
+                            const R xm = from_lower_lane(o), xp = from_upper_lane(o);
+                            const R below = j > 0 ? C[c ^ 1][PH(d)][j > 0 ? j - 1 : 0] : up;
+                            const R above = j + 1 < J ? C[c ^ 1][PH(d)][j + 1 < J ? j + 1 : 0] : dn;
+                            const R yp = sc ? above : o; // u[y+1]
+                            const R ym = sc ? o : below; // u[y-1]
+                            const R own = C[c][PH(d)][j];
+                            const R fv = F[c][PH(d)][j];
+                            // mg_1.cl:35-42: neighbours summed in R in this order, times the
+                            // double literal 1.0/6.0, rounded to R
+                            const R val = (1.0 / 6.0) * (xp + xm + yp + ym + C[c][PH(d - 1)][j] + C[c][PH(d + 1)][j] - fv);
+                            // mg_1.cl:69; for omega == 1 the double expression reduces exactly
+                            // to val + 0*own evaluated in R
+                            R gs = OMEGA1 ? val + (R)0 * own : (R)(val * omega + (1.0 - omega) * own);
+                            // Keep the update unconditional: left alone, the compiler sinks it
+                            // under a branch on take_gs, and the exec-mask blocks that result
+                            // serialise the independent updates of a step and their LDS reads.
+                            asm("" : "+v"(gs));
+                            const bool take_gs = FAST ? interior[c][j] : (interior[c][j] && zin);
+                            const bool take_f = FAST ? latfix[c][j] : (interior[c][j] ? zdir : latdir[c][j]);
+                            C[c][PH(d)][j] = take_gs ? gs : (take_f ? fv : own);
                         }
                     }
                 }
-                // ---- plane t - 2(ITERS-1) is final: store the tile's interior -------------------
-                const int zf = t - 2 * (ITERS - 1);
+                // ---- plane i - NP is final: store the tile's interior ----------------------------
+                const int zf = i - NP;
                 if (FAST || zf >= 0) {
                     const desc_t ro = plane_desc(out + slab * zf, plane_bytes);
 #pragma unroll
                     for (int r = 0; r < SR; ++r)
-                        buf_store_hidden(((r & 1) ^ s0) ? C[1][PH(2 * ITERS - 1)][r / 2] : C[0][PH(2 * ITERS - 1)][r / 2],
-                                         ro, soff[r]);
+                        buf_store_hidden(((r & 1) ^ s0) ? C[1][PH(NP)][r / 2] : C[0][PH(NP)][r / 2], ro, soff[r]);
                 }
 #undef PH
             }
@@ -249,11 +251,14 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
     // every other path drains all prefetches before it reaches one.
     auto drain = [&]() {
 #pragma unroll
-        for (int k = 0; k < PF; ++k)
+        for (int k = 0; k < PD; ++k)
             wait_slot<0>(pu[k], pf[k]);
     };
-    // first step of a group: t - 2(ITERS-1) >= 1; last step: t < zlast, t < zlim, i + PF <= zlast
-    auto is_fast = [&](int i0) { return i0 >= 2 * ITERS && i0 + PF - 2 < zlim && i0 + 2 * PF - 1 <= zlast; };
+    // first step of a group: deepest plane i0 - NP >= 1; last step: shallowest plane i0 + UN - 2 below
+    // the top face and zlim, prefetched plane i0 + UN - 1 + PD <= zlast
+    auto is_fast = [&](int i0) {
+        return i0 >= NP + 1 && i0 + UN - 2 < zlim && i0 + UN - 2 < zlast && i0 + UN - 1 + PD <= zlast;
+    };
     // The fast groups run in a loop of their own: with a single path through the loop body the
     // register allocator keeps every ring and prefetch register in place across the back edge
     // (a shared loop made it copy the freshly requested prefetch registers at the latch, which
@@ -262,18 +267,18 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
         if (is_fast(i0)) {
             do {
                 group(std::true_type{}, i0);
-                i0 += PF;
+                i0 += UN;
             } while (is_fast(i0));
             drain();
         } else {
             group(std::false_type{}, i0);
-            i0 += PF;
+            i0 += UN;
             drain();
         }
     }
 }
 
-template <class R, int ITERS, int SR, int NW, int PFM>
+template <class R, int ITERS, int SR, int NW, int PD>
 mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, int zcount, hipStream_t hs)
 {
     constexpr int H = 2 * ITERS, OX = kWave - 2 * H, OY = NW * SR - 2 * H;
@@ -281,23 +286,23 @@ mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega,
     const int ntx = (g->nx + OX - 1) / OX, nty = (g->ny + OY - 1) / OY;
     const dim3 grid(ntx * nty);
     if (omega == (R)1)
-        k_smooth3d_fused<R, ITERS, SR, NW, PFM, true><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, omega, zcount, ntx);
+        k_smooth3d_fused<R, ITERS, SR, NW, PD, true><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, omega, zcount, ntx);
     else
-        k_smooth3d_fused<R, ITERS, SR, NW, PFM, false><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, omega, zcount, ntx);
+        k_smooth3d_fused<R, ITERS, SR, NW, PD, false><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, omega, zcount, ntx);
     MGRT_HIP(hipGetLastError());
     return MGRT_OK;
 }
 
 template <class R> struct Cfg;
 template <> struct Cfg<float> {
-    static constexpr int SR1 = 4, NW1 = 4, PF1 = 1; // one iteration per sweep: 3 planes prefetched
-    static constexpr int SR2 = 4, NW2 = 8, PF2 = 1; // two iterations per sweep: 5 planes prefetched
-    static constexpr int NWS2 = 8;                  // waves per block of the small-level shape
+    static constexpr int SR1 = 4, NW1 = 8, PF1 = 4; // one iteration per sweep: 4 planes prefetched
+    static constexpr int SR2 = 4, NW2 = 8, PF2 = 3; // two iterations per sweep: 3 planes prefetched
+    static constexpr int NWS2 = 8, PFS2 = 6;        // waves per block and prefetch depth of the small-level shape
 };
 template <> struct Cfg<double> {
-    static constexpr int SR1 = 4, NW1 = 4, PF1 = 1;
-    static constexpr int SR2 = 2, NW2 = 12, PF2 = 1;
-    static constexpr int NWS2 = 12;
+    static constexpr int SR1 = 4, NW1 = 4, PF1 = 4;
+    static constexpr int SR2 = 2, NW2 = 12, PF2 = 3;
+    static constexpr int NWS2 = 12, PFS2 = 3;
 };
 
 template <class R>
@@ -324,22 +329,24 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
         const int c = atoi(e);
         if (sizeof(R) == 4 && iters == 2) {
             switch (c) {
-            case 1: return launch<R, 2, 4, 4, 1>(g, out, in, f, omega, zcount, hs);
-            case 2: return launch<R, 2, 4, 6, 1>(g, out, in, f, omega, zcount, hs);
-            case 3: return launch<R, 2, 2, 16, 1>(g, out, in, f, omega, zcount, hs);
-            case 4: return launch<R, 2, 2, 8, 1>(g, out, in, f, omega, zcount, hs);
-            case 5: return launch<R, 2, 4, 16, 1>(g, out, in, f, omega, zcount, hs);
-            case 6: return launch<R, 2, 2, 12, 1>(g, out, in, f, omega, zcount, hs);
+            case 1: return launch<R, 2, 4, 8, 2>(g, out, in, f, omega, zcount, hs);
+            case 2: return launch<R, 2, 4, 6, 3>(g, out, in, f, omega, zcount, hs);
+            case 3: return launch<R, 2, 2, 16, 6>(g, out, in, f, omega, zcount, hs);
+            case 4: return launch<R, 2, 2, 8, 3>(g, out, in, f, omega, zcount, hs);
+            case 5: return launch<R, 2, 4, 16, 3>(g, out, in, f, omega, zcount, hs);
+            case 6: return launch<R, 2, 2, 12, 6>(g, out, in, f, omega, zcount, hs);
+            case 7: return launch<R, 2, 4, 12, 3>(g, out, in, f, omega, zcount, hs);
+            case 8: return launch<R, 2, 6, 6, 3>(g, out, in, f, omega, zcount, hs);
             }
         }
         if (sizeof(R) == 4 && iters == 1) {
             switch (c) {
-            case 1: return launch<R, 1, 4, 8, 1>(g, out, in, f, omega, zcount, hs);
-            case 2: return launch<R, 1, 2, 8, 2>(g, out, in, f, omega, zcount, hs);
-            case 3: return launch<R, 1, 2, 16, 2>(g, out, in, f, omega, zcount, hs);
-            case 4: return launch<R, 1, 8, 4, 1>(g, out, in, f, omega, zcount, hs);
-            case 5: return launch<R, 1, 4, 16, 1>(g, out, in, f, omega, zcount, hs);
-            case 6: return launch<R, 1, 8, 8, 1>(g, out, in, f, omega, zcount, hs);
+            case 1: return launch<R, 1, 4, 4, 4>(g, out, in, f, omega, zcount, hs);
+            case 2: return launch<R, 1, 2, 8, 8>(g, out, in, f, omega, zcount, hs);
+            case 3: return launch<R, 1, 2, 16, 4>(g, out, in, f, omega, zcount, hs);
+            case 4: return launch<R, 1, 8, 4, 2>(g, out, in, f, omega, zcount, hs);
+            case 5: return launch<R, 1, 4, 16, 4>(g, out, in, f, omega, zcount, hs);
+            case 6: return launch<R, 1, 8, 8, 2>(g, out, in, f, omega, zcount, hs);
             }
         }
     }
@@ -348,9 +355,9 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
     // strips of two rows halve the work a wave does per step (measured 25-30 % faster from 257^2 down).
     const bool small = (long long)g->nx * g->ny <= 300LL * 300LL;
     if (iters == 1)
-        return small ? launch<R, 1, 2, 8, 2>(g, out, in, f, omega, zcount, hs)
+        return small ? launch<R, 1, 2, 8, 4>(g, out, in, f, omega, zcount, hs)
                      : launch<R, 1, C::SR1, C::NW1, C::PF1>(g, out, in, f, omega, zcount, hs);
-    return small ? launch<R, 2, 2, C::NWS2, 1>(g, out, in, f, omega, zcount, hs)
+    return small ? launch<R, 2, 2, C::NWS2, C::PFS2>(g, out, in, f, omega, zcount, hs)
                  : launch<R, 2, C::SR2, C::NW2, C::PF2>(g, out, in, f, omega, zcount, hs);
 }
 
