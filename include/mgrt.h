@@ -110,6 +110,12 @@ mgrt_status mgrt_box_cells_host(int dim, int nx, int ny, int nz, const int face[
        alias in.  Replaces the launch loop of smoother_iterate (multigridsolver3D.cpp:124-131). */ \
     mgrt_status mgrt_smooth_sweep##S(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, \
                                      int iters, int zcount, mgrt_stream s);                        \
+    /* The same sweep, which also leaves r = residual of `out` (as mgrt_residual with               \
+       zero_unwritten) behind: smoother_iterate followed by compute_residuals                      \
+       (multigridsolver3D.cpp:50,61) in one pass over the fields.  Same restrictions. */           \
+    mgrt_status mgrt_smooth_sweep_residual##S(const mgrt_grid *g, R *out, R *r, const R *in,       \
+                                              const R *f, R omega, int iters, int zcount,          \
+                                              mgrt_stream s);                                      \
     /* r = f - A u on inner cells, f - u on Dirichlet cells; outer and Neumann cells of r are     \
        left untouched, or set to 0 when zero_unwritten != 0.  Replaces residual_kernel            \
        (mg_1.cl:111-133, mg_0.cl:105-126).  norm2 (device, may be NULL) receives sum(r*r) over    \

@@ -41,6 +41,10 @@ mgrt_status check_grid(const mgrt_grid *g, const char *who);
 
 constexpr int kMaxPartials = 1 << 16;
 
+// Levels of at most about 300^2 columns are bound by the latency of a z step of the fused smoother,
+// not by bandwidth: they get narrower strips, and carrying the residual pass along does not pay.
+inline bool latency_bound_level(const mgrt_grid &g) { return (long long)g.nx * g.ny <= 300LL * 300LL; }
+
 // Blocks are dealt to the 8 XCDs round-robin (blocks b and b+8 share an L2).  This bijective map
 // gives the blocks of one XCD consecutive work-item ids, so that neighbouring tiles, which touch
 // the same halo cells and cache lines, meet in one L2.  A speed matter only.

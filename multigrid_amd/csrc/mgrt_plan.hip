@@ -67,6 +67,7 @@ template <class R> struct K;
 template <> struct K<float> {
     static constexpr auto smooth = mgrt_smooth_f32;
     static constexpr auto sweep = mgrt_smooth_sweep_f32;
+    static constexpr auto sweep_res = mgrt_smooth_sweep_residual_f32;
     static constexpr auto residual = mgrt_residual_f32;
     static constexpr auto restrict_ = mgrt_restrict_f32;
     static constexpr auto resrestrict = mgrt_residual_restrict_f32;
@@ -76,6 +77,7 @@ template <> struct K<float> {
 template <> struct K<double> {
     static constexpr auto smooth = mgrt_smooth_f64;
     static constexpr auto sweep = mgrt_smooth_sweep_f64;
+    static constexpr auto sweep_res = mgrt_smooth_sweep_residual_f64;
     static constexpr auto residual = mgrt_residual_f64;
     static constexpr auto restrict_ = mgrt_restrict_f64;
     static constexpr auto resrestrict = mgrt_residual_restrict_f64;
@@ -88,9 +90,11 @@ template <> struct K<double> {
 bool sweepable(const mgrt_plan *p, const mgrt_grid &g) { return !p->desc.no_fuse && g.dim == 3 && g.cells == nullptr; }
 
 // `a` smoothing iterations on *cur, as `nsweeps` out-of-place fused sweeps that ping-pong between
-// *cur and *alt (nsweeps between ceil(a/2) and a), or in place when nsweeps == 0.
+// *cur and *alt (nsweeps between ceil(a/2) and a), or in place when nsweeps == 0.  With `res`, the
+// last sweep also leaves the residual of the result there (nsweeps > 0 only).
 template <class R>
-mgrt_status smooth_steps(mgrt_plan *p, mgrt_plan::Level &L, R *&cur, R *&alt, const R *f, R omega, int a, int nsweeps)
+mgrt_status smooth_steps(mgrt_plan *p, mgrt_plan::Level &L, R *&cur, R *&alt, const R *f, R omega, int a, int nsweeps,
+                         R *res = nullptr)
 {
     mgrt_stream s = (mgrt_stream)p->stream;
     const int zc = zcount_of(p, L.g);
@@ -99,7 +103,8 @@ mgrt_status smooth_steps(mgrt_plan *p, mgrt_plan::Level &L, R *&cur, R *&alt, co
     for (int i = 0; i < nsweeps; ++i) {
         // spread the iterations: the first (a - nsweeps) sweeps do two, the rest one
         const int n = i < a - nsweeps ? 2 : 1;
-        if (mgrt_status st = K<R>::sweep(&L.g, alt, cur, f, omega, n, zc, s))
+        if (mgrt_status st = res && i + 1 == nsweeps ? K<R>::sweep_res(&L.g, alt, res, cur, f, omega, n, zc, s)
+                                                     : K<R>::sweep(&L.g, alt, cur, f, omega, n, zc, s))
             return st;
         R *t = cur;
         cur = alt;
@@ -126,8 +131,10 @@ template <class R> mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R 
             else if (n1 < a1) ++n1;
         }
     }
+    // On bandwidth-bound levels the last pre-smoothing sweep carries the residual pass along.
+    const bool res_in_sweep = n1 > 0 && v > 0 && recurses(L.g) && !latency_bound_level(L.g) && !p->fuse_rr;
     if (a1 > 0)
-        if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a1, n1))
+        if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a1, n1, res_in_sweep ? (R *)L.r : nullptr))
             return st;
     if (recurses(L.g)) {
         mgrt_plan::Level &C = p->lv[l + 1];
@@ -140,8 +147,9 @@ template <class R> mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R 
                 if (mgrt_status st = K<R>::resrestrict(&L.g, &C.g, (R *)C.rhs, cur, f, 0, C.g.ny, s))
                     return st;
             } else {
-                if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, 0, L.g.ny, s))
-                    return st;
+                if (!(res_in_sweep && k == 0))
+                    if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, 0, L.g.ny, s))
+                        return st;
                 if (mgrt_status st = K<R>::restrict_(&L.g, &C.g, (R *)C.rhs, (const R *)L.r, 0, C.g.ny, s))
                     return st;
             }

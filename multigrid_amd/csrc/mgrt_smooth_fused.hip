@@ -41,22 +41,31 @@ namespace {
 
 constexpr int kWave = 64;
 
-template <class R, int ITERS, int SR, int NW, int PD, bool OMEGA1>
+//
+// RES adds one more pass, two planes behind the last colour pass, where every neighbour is final:
+// res = f - A out on inner points, f - out on Dirichlet points, 0 elsewhere (residual_kernel,
+// mg_1.cl:46-53,111-133, with the cells it leaves unwritten set to 0).  It costs one more ring of
+// halo and two more planes in the rings, and saves a separate pass over out and f.
+template <class R, int ITERS, int SR, int NW, int PD, bool OMEGA1, bool RES>
 __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const R *__restrict__ in,
                                                               R *__restrict__ out, const R *__restrict__ f,
-                                                              R omega, int zcount, int ntx)
+                                                              R *__restrict__ res, R omega, int zcount, int ntx)
 {
     static_assert(SR % 2 == 0, "rows are handled in pairs");
-    constexpr int H = 2 * ITERS, J = SR / 2, NP = 2 * ITERS, ND = NP + 2;
+    constexpr int NP = 2 * ITERS, J = SR / 2;
+    constexpr int H = NP + (RES ? 1 : 0);  // halo rings consumed
+    constexpr int DR = NP + 2;             // ring depth of the residual pass
+    constexpr int ND = RES ? NP + 4 : NP + 2, NSET = RES ? NP + 2 : NP;
     // The plane rings (period ND) and the prefetch ring (period PD) are addressed with indices that
     // are compile-time constants inside a time loop unrolled UN times, UN a multiple of both: plane
     // i lives in ring slot i % ND and prefetch slot i % PD, nothing is ever shifted.
     static_assert(ND % PD == 0 || PD % ND == 0, "prefetch depth and ring depth must divide the unrolled loop");
     constexpr int UN = ND > PD ? ND : PD;
-    constexpr int kYounger = SR + (PD - 1) * 3 * SR; // see wait_slot
+    constexpr int kStores = RES ? 2 * SR : SR;                    // per step
+    constexpr int kYounger = kStores + (PD - 1) * (2 * SR + kStores); // see wait_slot
     static_assert(kYounger < 64, "too many vector-memory operations in flight for a counted wait");
     constexpr int OX = kWave - 2 * H, OY = NW * SR - 2 * H;
-    __shared__ R bnd[2][NP][NW][2][kWave];
+    __shared__ R bnd[2][NSET][NW][2][kWave];
 
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
     // Blocks are dealt to the 8 XCDs round-robin (block b and b+8 share an L2).  Give every XCD a
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
     };
     drain0(); // the loop below starts from landed registers (see `drain`)
 
-    const int nsteps = g.nz + NP; // planes entering the ring: 0 .. nz+NP-1
+    const int nsteps = g.nz + (RES ? DR : NP); // planes entering the ring: the last one finishes plane nz-1
     const int zlim = zcount < g.nz ? zcount : g.nz;
     const int wu = w > 0 ? w - 1 : 0, wd = w + 1 < NW ? w + 1 : NW - 1;
     // One group of UN consecutive time steps, unrolled so that every ring index is a constant.
@@ -153,9 +162,9 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
 #define PH(d) ((((u) - (d)) % ND + ND) % ND) /* ring slot of depth d, i.e. of plane i - d */
                 const int ps = u % PD; // prefetch slot of plane i (a constant once the loop is unrolled)
                 // ---- plane i: prefetch registers -> ring slot -----------------------------------
-                // In a fast group every step issues 2*SR loads then SR stores, so the slot's loads
-                // have SR stores and PD-1 whole steps behind them; elsewhere steps may skip their
-                // stores, so wait for everything.
+                // In a fast group every step issues 2*SR loads then kStores stores, so the slot's
+                // loads have kStores stores and PD-1 whole steps behind them; elsewhere steps may
+                // skip their stores, so wait for everything.
                 if (FAST)
                     wait_slot<kYounger>(pu[ps], pf[ps]);
                 else
@@ -193,6 +202,13 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                     const int oc = ((d - 1) & 1) ^ 1;
                     bnd[par][d - 1][w][0][lane] = C[oc][PH(d)][0];
                     bnd[par][d - 1][w][1][lane] = C[oc][PH(d)][J - 1];
+                }
+                if (RES) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        bnd[par][NSET - 2 + c][w][0][lane] = C[c][PH(DR)][0];
+                        bnd[par][NSET - 2 + c][w][1][lane] = C[c][PH(DR)][J - 1];
+                    }
                 }
                 __syncthreads();
                 // ---- the passes: pass d = colour (d-1)%2 of iteration (d+1)/2 on plane i - d ----
@@ -234,11 +250,47 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                 }
                 // ---- plane i - NP is final: store the tile's interior ----------------------------
                 const int zf = i - NP;
-                if (FAST || zf >= 0) {
+                if (FAST || (zf >= 0 && zf <= zlast)) {
                     const desc_t ro = plane_desc(out + slab * zf, plane_bytes);
 #pragma unroll
                     for (int r = 0; r < SR; ++r)
                         buf_store_hidden(((r & 1) ^ s0) ? C[1][PH(NP)][r / 2] : C[0][PH(NP)][r / 2], ro, soff[r]);
+                }
+                // ---- residual of plane i - DR, whose neighbours are all final ---------------------
+                if (RES) {
+                    const int z = i - DR;
+                    if (FAST || (z >= 0 && z <= zlast)) {
+                        const int zcls = z == 0 ? g.face[4] : (z == zlast ? g.face[5] : MGRT_CELL_INNER);
+                        const bool zin = zcls == MGRT_CELL_INNER, zdir = zcls == MGRT_CELL_DIRICHLET;
+                        R rv[2][J];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const bool sc = (s0 ^ c) != 0;
+                            // first / last row of the other colour in the neighbouring strips
+                            const R up = bnd[par][NSET - 2 + (c ^ 1)][wu][1][lane];
+                            const R dn = bnd[par][NSET - 2 + (c ^ 1)][wd][0][lane];
+#pragma unroll
+                            for (int j = 0; j < J; ++j) {
+                                const R o = C[c ^ 1][PH(DR)][j];
+                                const R xm = from_lower_lane(o), xp = from_upper_lane(o);
+                                const R below = j > 0 ? C[c ^ 1][PH(DR)][j > 0 ? j - 1 : 0] : up;
+                                const R above = j + 1 < J ? C[c ^ 1][PH(DR)][j + 1 < J ? j + 1 : 0] : dn;
+                                const R yp = sc ? above : o, ym = sc ? o : below;
+                                const R own = C[c][PH(DR)][j], fv = F[c][PH(DR)][j];
+                                // mg_1.cl:46-53: integer literal, pure R arithmetic
+                                R vi = fv - (xp + xm + yp + ym + C[c][PH(DR - 1)][j] + C[c][PH(DR + 1)][j] - 6 * own);
+                                asm("" : "+v"(vi));
+                                const R vd = fv - own;
+                                const bool is_in = FAST ? interior[c][j] : (interior[c][j] && zin);
+                                const bool is_dir = FAST ? latfix[c][j] : (interior[c][j] ? zdir : latdir[c][j]);
+                                rv[c][j] = is_in ? vi : (is_dir ? vd : (R)0);
+                            }
+                        }
+                        const desc_t rr = plane_desc(res + slab * z, plane_bytes);
+#pragma unroll
+                        for (int r = 0; r < SR; ++r)
+                            buf_store_hidden(((r & 1) ^ s0) ? rv[1][r / 2] : rv[0][r / 2], rr, soff[r]);
+                    }
                 }
 #undef PH
             }
@@ -254,10 +306,11 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
         for (int k = 0; k < PD; ++k)
             wait_slot<0>(pu[k], pf[k]);
     };
-    // first step of a group: deepest plane i0 - NP >= 1; last step: shallowest plane i0 + UN - 2 below
-    // the top face and zlim, prefetched plane i0 + UN - 1 + PD <= zlast
+    // first step of a group: deepest plane (i0 - NP, or i0 - DR with the residual pass) >= 1; last
+    // step: shallowest plane i0 + UN - 2 below the top face and zlim, prefetched plane
+    // i0 + UN - 1 + PD <= zlast
     auto is_fast = [&](int i0) {
-        return i0 >= NP + 1 && i0 + UN - 2 < zlim && i0 + UN - 2 < zlast && i0 + UN - 1 + PD <= zlast;
+        return i0 >= (RES ? DR : NP) + 1 && i0 + UN - 2 < zlim && i0 + UN - 2 < zlast && i0 + UN - 1 + PD <= zlast;
     };
     // The fast groups run in a loop of their own: with a single path through the loop body the
     // register allocator keeps every ring and prefetch register in place across the back edge
@@ -278,17 +331,18 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
     }
 }
 
-template <class R, int ITERS, int SR, int NW, int PD>
-mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, int zcount, hipStream_t hs)
+template <class R, int ITERS, int SR, int NW, int PD, bool RES = false>
+mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, int zcount, hipStream_t hs,
+                   R *res = nullptr)
 {
-    constexpr int H = 2 * ITERS, OX = kWave - 2 * H, OY = NW * SR - 2 * H;
+    constexpr int H = 2 * ITERS + (RES ? 1 : 0), OX = kWave - 2 * H, OY = NW * SR - 2 * H;
     static_assert(OY > 0, "tile has no interior");
     const int ntx = (g->nx + OX - 1) / OX, nty = (g->ny + OY - 1) / OY;
     const dim3 grid(ntx * nty);
     if (omega == (R)1)
-        k_smooth3d_fused<R, ITERS, SR, NW, PD, true><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, omega, zcount, ntx);
+        k_smooth3d_fused<R, ITERS, SR, NW, PD, true, RES><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx);
     else
-        k_smooth3d_fused<R, ITERS, SR, NW, PD, false><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, omega, zcount, ntx);
+        k_smooth3d_fused<R, ITERS, SR, NW, PD, false, RES><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx);
     MGRT_HIP(hipGetLastError());
     return MGRT_OK;
 }
@@ -297,7 +351,7 @@ template <class R> struct Cfg;
 template <> struct Cfg<float> {
     static constexpr int SR1 = 4, NW1 = 8, PF1 = 4; // one iteration per sweep: 4 planes prefetched
     static constexpr int SR2 = 4, NW2 = 8, PF2 = 3; // two iterations per sweep: 3 planes prefetched
-    static constexpr int NWS2 = 8, PFS2 = 6;        // waves per block and prefetch depth of the small-level shape
+    static constexpr int NWS2 = 8, PFS2 = 3;        // waves per block and prefetch depth of the small-level shape
 };
 template <> struct Cfg<double> {
     static constexpr int SR1 = 4, NW1 = 4, PF1 = 4;
@@ -305,14 +359,16 @@ template <> struct Cfg<double> {
     static constexpr int NWS2 = 12, PFS2 = 3;
 };
 
+// res == nullptr: the sweep alone; otherwise the sweep with the residual pass.
 template <class R>
 mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, int iters, int zcount,
-                         mgrt_stream s)
+                         mgrt_stream s, R *res = nullptr)
 {
     if (mgrt_status st = require_init()) return st;
     if (mgrt_status st = check_grid(g, "mgrt_smooth_sweep")) return st;
     MGRT_REQUIRE(out && in && f, "mgrt_smooth_sweep: null field");
     MGRT_REQUIRE(out != in && out != f, "mgrt_smooth_sweep: out must not alias in or f");
+    MGRT_REQUIRE(res != out && res != in && res != f, "mgrt_smooth_sweep_residual: r must not alias another field");
     MGRT_REQUIRE(zcount >= 0 && zcount <= g->nz, "mgrt_smooth_sweep: zcount %d outside [0,%d]", zcount, g->nz);
     MGRT_REQUIRE(g->slab < (1LL << 30), "mgrt_smooth_sweep: plane too large for 32-bit in-plane offsets");
     if (g->dim != 3)
@@ -351,9 +407,16 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
         }
     }
 #endif
-    // Below about 300^2 columns a level is bound by the latency of a time step, not by bandwidth:
-    // strips of two rows halve the work a wave does per step (measured 25-30 % faster from 257^2 down).
-    const bool small = (long long)g->nx * g->ny <= 300LL * 300LL;
+    // strips of two rows halve the work a wave does per step (measured 25-30 % faster from 257^2 down)
+    const bool small = latency_bound_level(*g);
+    if (res) {
+        constexpr bool wide = sizeof(R) == 4; // strips of four rows only with 4-byte elements (registers)
+        if (iters == 1)
+            return small || !wide ? launch<R, 1, 2, 8, 3, true>(g, out, in, f, omega, zcount, hs, res)
+                                  : launch<R, 1, wide ? 4 : 2, 8, 3, true>(g, out, in, f, omega, zcount, hs, res);
+        return small || !wide ? launch<R, 2, 2, 8, 4, true>(g, out, in, f, omega, zcount, hs, res)
+                              : launch<R, 2, wide ? 4 : 2, 8, 4, true>(g, out, in, f, omega, zcount, hs, res);
+    }
     if (iters == 1)
         return small ? launch<R, 1, 2, 8, 4>(g, out, in, f, omega, zcount, hs)
                      : launch<R, 1, C::SR1, C::NW1, C::PF1>(g, out, in, f, omega, zcount, hs);
@@ -367,6 +430,24 @@ extern "C" mgrt_status mgrt_smooth_sweep_f32(const mgrt_grid *g, float *out, con
                                              float omega, int iters, int zcount, mgrt_stream s)
 {
     return smooth_sweep<float>(g, out, in, f, omega, iters, zcount, s);
+}
+
+extern "C" mgrt_status mgrt_smooth_sweep_residual_f32(const mgrt_grid *g, float *out, float *r, const float *in,
+                                                      const float *f, float omega, int iters, int zcount,
+                                                      mgrt_stream s)
+{
+    if (!r)
+        return fail(MGRT_E_INVALID, "mgrt_smooth_sweep_residual: null field");
+    return smooth_sweep<float>(g, out, in, f, omega, iters, zcount, s, r);
+}
+
+extern "C" mgrt_status mgrt_smooth_sweep_residual_f64(const mgrt_grid *g, double *out, double *r, const double *in,
+                                                      const double *f, double omega, int iters, int zcount,
+                                                      mgrt_stream s)
+{
+    if (!r)
+        return fail(MGRT_E_INVALID, "mgrt_smooth_sweep_residual: null field");
+    return smooth_sweep<double>(g, out, in, f, omega, iters, zcount, s, r);
 }
 
 extern "C" mgrt_status mgrt_smooth_sweep_f64(const mgrt_grid *g, double *out, const double *in, const double *f,

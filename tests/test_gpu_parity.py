@@ -189,6 +189,55 @@ def test_fused_residual_restrict_matches_oracle(dev, mgo, dt, shape):
         assert bits_equal(out.cpu().numpy(), ref), (shape, faces, dmap is not None)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", [(9, 11, 13), (5, 5, 5), (33, 17, 65), (20, 67, 129), (17, 130, 70), (40, 60, 58),
+                                   (70, 140, 150)],
+                         ids=lambda s: "x".join(map(str, s[::-1])))
+def test_fused_sweep_with_residual_matches_sweep_then_residual(dev, dt, shape):
+    """out and r of the sweep that carries the residual pass against the sweep followed by the
+    residual kernel (both already checked against the oracle), bit for bit."""
+    import torch
+    from multigrid_amd import _lib as L
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    torch.manual_seed(abs(hash(shape)) % 2**31)
+    for faces in ((2,) * 6, (2, 3, 3, 2, 2, 3), (3, 3, 2, 2, 1, 2)):
+        g = L.grid(shape, faces=faces)
+        u = torch.randn(shape, device=dev, dtype=tdt)
+        f = torch.randn(shape, device=dev, dtype=tdt)
+        for iters in (1, 2):
+            for omega, zc in ((1.0, None), (0.8, shape[0] // 2 + shape[0] % 2)):
+                want_u = torch.empty_like(u)
+                L.smooth_sweep(g, want_u, u, f, omega, iters, zc)
+                want_r = torch.full_like(u, 7.0)
+                L.residual(g, want_r, want_u, f, True)
+                got_u, got_r = torch.full_like(u, 5.0), torch.full_like(u, 9.0)
+                L.smooth_sweep_residual(g, got_u, got_r, u, f, omega, iters, zc)
+                assert torch.equal(got_u, want_u), (shape, faces, iters, omega)
+                assert torch.equal(got_r.view(torch.uint8), want_r.view(torch.uint8)), (shape, faces, iters, omega)
+
+
+@pytest.mark.parametrize("v", [1, 2], ids=["V", "W"])
+def test_cycle_on_wide_planes_matches_oracle(dev, mgo, v):
+    """Levels with more than 300^2 columns take the sweep that carries the residual pass: two
+    cycles on 513 x 513 x 9 (three levels, the two finest wide) against the oracle, bit for bit."""
+    import torch
+    from multigrid_amd import _lib as L
+    shape = (9, 513, 513)
+    rng = np.random.default_rng(17)
+    f = rng.standard_normal(shape).astype(np.float32)
+    u = rng.standard_normal(shape).astype(np.float32)
+    ref = u.copy()
+    mgo.mg(ref, f, np.float32(0.9), 2, 2, v, 2, True)
+    du, df = to_dev(u, dev), to_dev(f, dev)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        plan = L.Plan(shape, torch.float32, zfull=True, use_graph=True)
+        plan.vcycle(du, df, 0.9, 2, 2, v, 2)
+        plan.close()
+    torch.cuda.synchronize()
+    assert bits_equal(du.cpu().numpy(), ref)
+
+
 def test_fused_sweep_on_a_slab(dev):
     """Rows of a y-slab (odd global offset, so the colours are shifted) equal the whole-grid rows
     wherever the halo of 2*iters rows was available."""

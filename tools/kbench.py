@@ -54,6 +54,8 @@ def main():
     timeit("smooth_sweep x1", lambda: L.smooth_sweep(g, o, u, f, 1.0, 1), 3 * N * w)
     timeit("smooth_sweep x2", lambda: L.smooth_sweep(g, o, u, f, 1.0, 2), 3 * N * w)
     timeit("smooth_sweep x2 omega.8", lambda: L.smooth_sweep(g, o, u, f, 0.8, 2), 3 * N * w)
+    timeit("smooth_sweep+res x2", lambda: L.smooth_sweep_residual(g, o, r, u, f, 1.0, 2), 4 * N * w)
+    timeit("smooth_sweep+res x1", lambda: L.smooth_sweep_residual(g, o, r, u, f, 1.0, 1), 4 * N * w)
     timeit("residual", lambda: L.residual(g, r, u, f), 3 * N * w)
     n2 = torch.zeros(1, device="cuda", dtype=torch.float64)
     timeit("residual+norm", lambda: L.residual(g, r, u, f, norm2=n2), 3 * N * w)
