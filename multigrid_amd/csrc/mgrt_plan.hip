@@ -94,7 +94,7 @@ bool sweepable(const mgrt_plan *p, const mgrt_grid &g) { return !p->desc.no_fuse
 // last sweep also leaves the residual of the result there (nsweeps > 0 only).
 template <class R>
 mgrt_status smooth_steps(mgrt_plan *p, mgrt_plan::Level &L, R *&cur, R *&alt, const R *f, R omega, int a, int nsweeps,
-                         R *res = nullptr)
+                         R *res = nullptr, bool cur_is_zero = false)
 {
     mgrt_stream s = (mgrt_stream)p->stream;
     const int zc = zcount_of(p, L.g);
@@ -103,8 +103,10 @@ mgrt_status smooth_steps(mgrt_plan *p, mgrt_plan::Level &L, R *&cur, R *&alt, co
     for (int i = 0; i < nsweeps; ++i) {
         // spread the iterations: the first (a - nsweeps) sweeps do two, the rest one
         const int n = i < a - nsweeps ? 2 : 1;
-        if (mgrt_status st = res && i + 1 == nsweeps ? K<R>::sweep_res(&L.g, alt, res, cur, f, omega, n, zc, s)
-                                                     : K<R>::sweep(&L.g, alt, cur, f, omega, n, zc, s))
+        // a field known to be all zeros is not read (and was not cleared): the kernel takes NULL
+        const R *in = cur_is_zero && i == 0 ? nullptr : cur;
+        if (mgrt_status st = res && i + 1 == nsweeps ? K<R>::sweep_res(&L.g, alt, res, in, f, omega, n, zc, s)
+                                                     : K<R>::sweep(&L.g, alt, in, f, omega, n, zc, s))
             return st;
         R *t = cur;
         cur = alt;
@@ -115,7 +117,10 @@ mgrt_status smooth_steps(mgrt_plan *p, mgrt_plan::Level &L, R *&cur, R *&alt, co
 
 // iterate(), multigridsolver3D.cpp:41-80, on level l with unknown u and right-hand side f.
 // The result is left in u.
-template <class R> mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int a2, int v)
+// u_is_zero: u stands for the cleared unknown of zero_mem (:59) but has not been cleared; it is
+// either never read (first sweep out of place) or cleared here.
+template <class R>
+mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int a2, int v, bool u_is_zero = false)
 {
     mgrt_plan::Level &L = p->lv[l];
     mgrt_stream s = (mgrt_stream)p->stream;
@@ -131,16 +136,19 @@ template <class R> mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R 
             else if (n1 < a1) ++n1;
         }
     }
+    if (u_is_zero && n1 == 0) {
+        if (mgrt_status st = mgrt_zero(u, L.n * sizeof(R), s))
+            return st;
+        u_is_zero = false;
+    }
     // On bandwidth-bound levels the last pre-smoothing sweep carries the residual pass along.
     const bool res_in_sweep = n1 > 0 && v > 0 && recurses(L.g) && !latency_bound_level(L.g) && !p->fuse_rr;
     if (a1 > 0)
-        if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a1, n1, res_in_sweep ? (R *)L.r : nullptr))
+        if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a1, n1, res_in_sweep ? (R *)L.r : nullptr, u_is_zero))
             return st;
     if (recurses(L.g)) {
         mgrt_plan::Level &C = p->lv[l + 1];
         for (int k = 0; k < v; ++k) {
-            if (mgrt_status st = mgrt_zero(C.e, C.n * sizeof(R), s)) // zero_mem(i), :59
-                return st;
             // outer/Neumann cells of the residual are defined as 0 (the reference reads
             // uninitialised memory there)
             if (L.g.dim == 3 && p->fuse_rr) {
@@ -153,7 +161,7 @@ template <class R> mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R 
                 if (mgrt_status st = K<R>::restrict_(&L.g, &C.g, (R *)C.rhs, (const R *)L.r, 0, C.g.ny, s))
                     return st;
             }
-            if (mgrt_status st = iterate<R>(p, l + 1, (R *)C.e, (const R *)C.rhs, omega, a1, a2, v))
+            if (mgrt_status st = iterate<R>(p, l + 1, (R *)C.e, (const R *)C.rhs, omega, a1, a2, v, true)) // zero_mem(i), :59
                 return st;
             // in place: same values as the out-of-place kernel followed by the handle swap (:70-72)
             if (mgrt_status st = K<R>::correct(&L.g, &C.g, cur, cur, (const R *)C.e, 0, L.g.ny, s))

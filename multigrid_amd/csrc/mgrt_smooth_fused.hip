@@ -87,6 +87,9 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
     // (a lateral face, or OUTER outside the grid).
     constexpr unsigned kDrop = 0x80000000u;
     const unsigned plane_bytes = (unsigned)(g.pitch * (long long)g.ny * (long long)sizeof(R));
+    // in == nullptr stands for a field of zeros: a descriptor of length 0 makes every load return 0
+    const R *inb = in ? in : f;
+    const unsigned in_bytes = in ? plane_bytes : 0u;
     unsigned off[SR], soff[SR];
     int rowcls[SR];
 #pragma unroll
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
 #pragma unroll
     for (int k = 0; k < PD; ++k) {
         const long long zo = slab * (k < zlast ? k : zlast);
-        const desc_t ru = plane_desc(in + zo, plane_bytes), rf = plane_desc(f + zo, plane_bytes);
+        const desc_t ru = plane_desc(inb + zo, in_bytes), rf = plane_desc(f + zo, plane_bytes);
 #pragma unroll
         for (int r = 0; r < SR; ++r) {
             buf_load_hidden(pu[k][r], ru, off[r]);
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                 { // plane i + PD -> prefetch slot ps
                     const int zn = i + PD;
                     const long long zo = slab * (FAST || zn < zlast ? zn : zlast);
-                    const desc_t ru = plane_desc(in + zo, plane_bytes), rf = plane_desc(f + zo, plane_bytes);
+                    const desc_t ru = plane_desc(inb + zo, in_bytes), rf = plane_desc(f + zo, plane_bytes);
 #pragma unroll
                     for (int r = 0; r < SR; ++r) {
                         buf_load_hidden(pu[ps][r], ru, off[r]);
@@ -366,9 +369,9 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
 {
     if (mgrt_status st = require_init()) return st;
     if (mgrt_status st = check_grid(g, "mgrt_smooth_sweep")) return st;
-    MGRT_REQUIRE(out && in && f, "mgrt_smooth_sweep: null field");
+    MGRT_REQUIRE(out && f, "mgrt_smooth_sweep: null field");
     MGRT_REQUIRE(out != in && out != f, "mgrt_smooth_sweep: out must not alias in or f");
-    MGRT_REQUIRE(res != out && res != in && res != f, "mgrt_smooth_sweep_residual: r must not alias another field");
+    MGRT_REQUIRE(!res || (res != out && res != in && res != f), "mgrt_smooth_sweep_residual: r must not alias another field");
     MGRT_REQUIRE(zcount >= 0 && zcount <= g->nz, "mgrt_smooth_sweep: zcount %d outside [0,%d]", zcount, g->nz);
     MGRT_REQUIRE(g->slab < (1LL << 30), "mgrt_smooth_sweep: plane too large for 32-bit in-plane offsets");
     if (g->dim != 3)
