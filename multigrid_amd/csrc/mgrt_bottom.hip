@@ -1,0 +1,334 @@
+// mgrt_bottom.hip -- the coarsest levels of a 3D cycle in one launch.
+//
+// From about 17^3 points down a level is a handful of microseconds of work, and a V(2,2) cycle
+// spends six launches on it: the cycle is then bound by launch latency.  This kernel runs
+// iterate() (multigridsolver3D.cpp:41-80) for the bottom of the hierarchy as ONE workgroup with
+// every array of every level in LDS: the colour passes of the smoother in place (mg_1.cl:29-43,
+// 56-104; a thread owns a column and marches z, as k_smooth3d_pass does), residual (mg_1.cl:46-53,
+// 111-133), restriction (mg_1.cl:146-190) and correction (mg_1.cl:200-233), separated by
+// workgroup barriers.  Expressions and operand order are those of the per-step kernels in
+// mgrt_kernels.hip, so the values are the same bit for bit.  Analytic box domains only.
+#include "mgrt_internal.h"
+
+using namespace mgrt;
+
+namespace {
+
+constexpr int kMaxLev = 8, kThreads = 1024;
+
+struct BottomArgs {
+    int nlev;
+    int nx[kMaxLev], ny[kMaxLev], nz[kMaxLev];
+    int face[6];
+    int zfull, a1, a2, v;
+};
+
+struct Lvl {
+    int nx, ny, nz, p, s, n, zcount;
+};
+
+__device__ __forceinline__ int box_class(const Lvl &L, const int (&face)[6], int x, int y, int z)
+{
+    // same order as cell_class<3, false>
+    if (y == 0) return face[2];
+    if (y == L.ny - 1) return face[3];
+    if (x == 0) return face[0];
+    if (x == L.nx - 1) return face[1];
+    if (z == 0) return face[4];
+    if (z == L.nz - 1) return face[5];
+    return MGRT_CELL_INNER;
+}
+
+__device__ __forceinline__ bool border_class(int t) { return t == MGRT_CELL_DIRICHLET || t == MGRT_CELL_NEUMANN; }
+
+template <class R> __device__ __forceinline__ R dot4b(R a0, R a1, R a2, R a3, R b0, R b1, R b2, R b3)
+{
+    return a0 * b0 + a1 * b1 + a2 * b2 + a3 * b3;
+}
+
+template <class R>
+__global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_out, const R *u_in, const R *f_in, R omega)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    R *const base = reinterpret_cast<R *>(smem);
+    // Level geometry and array placement are recomputed from the kernel arguments (scalar loads)
+    // wherever they are needed: arrays of pointers indexed by a run-time level would live in
+    // scratch memory.  Level m occupies 3 arrays of n_m elements (u, f, r), the last one 2.
+    auto level = [&](int l) {
+        Lvl L;
+        L.nx = A.nx[l], L.ny = A.ny[l], L.nz = A.nz[l];
+        L.p = L.nx, L.s = L.nx * L.ny, L.n = L.s * L.nz;
+        L.zcount = A.zfull ? L.nz : L.nz / 2 + L.nz % 2; // multigridsolver3D.cpp:121
+        return L;
+    };
+    auto u_of = [&](int l) {
+        int off = 0;
+        for (int m = 0; m < l; ++m)
+            off += 3 * A.nx[m] * A.ny[m] * A.nz[m];
+        return base + off;
+    };
+    const int tid = threadIdx.x;
+    const int(&face)[6] = A.face;
+
+    {
+        const int n0 = A.nx[0] * A.ny[0] * A.nz[0];
+        for (int i = tid; i < n0; i += kThreads) {
+            base[i] = u_in ? u_in[i] : (R)0;
+            base[n0 + i] = f_in[i];
+        }
+    }
+    __syncthreads();
+
+    // `iters` smoothing iterations on level l, in place (smoother_iterate, multigridsolver3D.cpp:111-132)
+    auto smooth = [&](int l, int iters) {
+        const Lvl L = level(l);
+        R *u = u_of(l);
+        const R *f = u + L.n;
+        const int hx = (L.nx + 1) / 2;
+        const int zload = L.zcount < L.nz ? L.zcount + 1 : L.nz;
+        for (int it = 0; it < 2 * iters; ++it) {
+            const int odd = it & 1;
+            for (int idx = tid; idx < hx * L.ny; idx += kThreads) {
+                const int y = idx / hx, x = 2 * (idx % hx) + ((odd + y) & 1);
+                if (x >= L.nx)
+                    continue;
+                // class of the column where it does not depend on z, else -1
+                const int lat = y == 0 ? face[2] : y == L.ny - 1 ? face[3] : x == 0 ? face[0] : x == L.nx - 1 ? face[1] : -1;
+                const int col = x + L.p * y;
+                // the in-plane neighbours have the other colour and do not change during this
+                // pass: plane z+1 is fetched while plane z is computed
+                const bool gather = lat < 0; // only inner points read neighbours
+                struct Plane {
+                    R xp, xm, yp, ym, f, own;
+                };
+                // raw values only: summing here would wait for the loads one step early
+                auto fetch = [&](int z) {
+                    const int b = col + L.s * z;
+                    Plane v;
+                    v.own = u[b];
+                    v.f = f[b];
+                    v.xp = v.xm = v.yp = v.ym = 0;
+                    if (gather) {
+                        v.xp = u[b + 1];
+                        v.xm = u[b - 1];
+                        v.yp = u[b + L.p];
+                        v.ym = u[b - L.p];
+                    }
+                    return v;
+                };
+                Plane cur = {0, 0, 0, 0, 0, 0};
+                R below = 0;
+                if (L.zcount > 0)
+                    cur = fetch(0);
+                for (int z = 0; z < L.zcount; ++z) {
+                    Plane nxt = {0, 0, 0, 0, 0, 0};
+                    if (z + 1 < zload)
+                        nxt = fetch(z + 1);
+                    const int t = lat >= 0 ? lat : (z == 0 ? face[4] : z == L.nz - 1 ? face[5] : MGRT_CELL_INNER);
+                    R next = cur.own;
+                    if (t == MGRT_CELL_INNER) {
+                        const R above = z + 1 < zload ? nxt.own : (R)0;
+                        const R val = (1.0 / 6.0) * (cur.xp + cur.xm + cur.yp + cur.ym + above + below - cur.f);
+                        next = val * omega + (1.0 - omega) * cur.own;
+                        u[col + L.s * z] = next;
+                    } else if (t == MGRT_CELL_DIRICHLET) {
+                        next = cur.f;
+                        u[col + L.s * z] = next;
+                    }
+                    below = next;
+                    cur = nxt;
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    auto residual = [&](int l) {
+        const Lvl L = level(l);
+        const R *u = u_of(l), *f = u + L.n;
+        R *r = u_of(l) + 2 * L.n;
+        for (int i = tid; i < L.n; i += kThreads) {
+            const int x = i % L.nx, y = (i / L.nx) % L.ny, z = i / L.s;
+            const int t = box_class(L, face, x, y, z);
+            R v = 0;
+            if (t == MGRT_CELL_INNER)
+                v = f[i] - (u[i + 1] + u[i - 1] + u[i + L.p] + u[i - L.p] + u[i + L.s] + u[i - L.s] - 6 * u[i]);
+            else if (t == MGRT_CELL_DIRICHLET)
+                v = f[i] - u[i];
+            r[i] = v;
+        }
+        __syncthreads();
+    };
+
+    // F[l+1] = Restrict(Rs[l]); U[l+1] = 0
+    auto restrict_zero = [&](int l) {
+        const Lvl Lf = level(l), Lc = level(l + 1);
+        const R *rf = u_of(l) + 2 * Lf.n;
+        R *e = u_of(l + 1), *rc = e + Lc.n;
+        const int p = Lf.p, s = Lf.s;
+        for (int d = tid; d < Lc.n; d += kThreads) {
+            const int i = d % Lc.nx, j = (d / Lc.nx) % Lc.ny, k = d / Lc.s;
+            const int x = 2 * i, y = 2 * j, z = 2 * k;
+            const R *c = rf + x + p * y + s * z;
+            const bool on_face = x == 0 || x == Lf.nx - 1 || y == 0 || y == Lf.ny - 1 || z == 0 || z == Lf.nz - 1;
+            bool border = on_face || border_class(box_class(Lf, face, x, y, z));
+            if (!border) {
+                border = border_class(box_class(Lf, face, x + 1, y, z)) || border_class(box_class(Lf, face, x, y + 1, z)) ||
+                         border_class(box_class(Lf, face, x + 1, y + 1, z));
+                if (!border)
+                    border = border_class(box_class(Lf, face, x, y, z + 1)) ||
+                             border_class(box_class(Lf, face, x + 1, y, z + 1)) ||
+                             border_class(box_class(Lf, face, x, y + 1, z + 1)) ||
+                             border_class(box_class(Lf, face, x + 1, y + 1, z + 1));
+            }
+            R val;
+            if (border) {
+                val = c[0];
+            } else {
+                val = 1.0 / 64.0 * (c[s + p + 1] + c[s + p - 1] + c[s - p + 1] + c[s - p - 1] + c[-s + p + 1] +
+                                    c[-s + p - 1] + c[-s - p + 1] + c[-s - p - 1]) +
+                      1.0 / 32.0 * (c[p + 1] + c[p - 1] + c[-p + 1] + c[-p - 1] + c[-s + p] + c[-s - p] + c[-s + 1] +
+                                    c[-s - 1] + c[s + p] + c[s - p] + c[s + 1] + c[s - 1]) +
+                      1.0 / 16.0 * (c[p] + c[-p] + c[1] + c[-1] + c[s] + c[-s]) + 1.0 / 8.0 * (c[0]);
+            }
+            rc[d] = val;
+            e[d] = 0;
+        }
+        __syncthreads();
+    };
+
+    // U[l] += 4 * P(U[l+1]) (residual_correct_kernel, in place)
+    auto correct = [&](int l) {
+        const Lvl Lf = level(l), Lc = level(l + 1);
+        R *u = u_of(l);
+        const R *e = u_of(l + 1);
+        const int cp = Lc.p, cs = Lc.s;
+        for (int d = tid; d < Lf.n; d += kThreads) {
+            const int x = d % Lf.nx, y = (d / Lf.nx) % Lf.ny, z = d / Lf.s;
+            const int ci = x / 2, cj = y / 2, ck = z / 2;
+            const int ci1 = ci + 1 < Lc.nx ? ci + 1 : ci;
+            const int cj1 = cj + 1 < Lc.ny ? cj + 1 : cj;
+            const int ck1 = ck + 1 < Lc.nz ? ck + 1 : ck;
+            const R *e0 = e + cs * ck, *e1 = e + cs * ck1;
+            R val;
+            if (border_class(box_class(Lf, face, x, y, z))) {
+                val = e0[ci + cp * cj];
+            } else {
+                const R wu = 0.5 * (x % 2), ww = 0.5 * (y % 2), wv = 0.5 * (z % 2);
+                const R n10 = (1.0 - wu) * (1.0 - ww) * (1.0 - wv), n11 = (1.0 - ww) * wu * (1.0 - wv),
+                        n12 = (1.0 - wu) * ww * (1.0 - wv), n13 = ww * wu * (1.0 - wv);
+                const R n20 = (1.0 - wu) * (1.0 - ww) * wv, n21 = (1.0 - ww) * wu * wv, n22 = (1.0 - wu) * ww * wv,
+                        n23 = ww * wu * wv;
+                val = dot4b<R>(e0[ci + cp * cj], e0[ci1 + cp * cj], e0[ci + cp * cj1], e0[ci1 + cp * cj1], n10, n11, n12,
+                               n13) +
+                      dot4b<R>(e1[ci + cp * cj], e1[ci1 + cp * cj], e1[ci + cp * cj1], e1[ci1 + cp * cj1], n20, n21, n22,
+                               n23);
+            }
+            u[d] = u[d] + val * 4;
+        }
+        __syncthreads();
+    };
+
+    // iterate() without recursion: walk down smoothing, walk up correcting; k[l] counts the coarse
+    // solves done on level l.  Control flow is uniform over the workgroup.
+    unsigned long long kpack = 0; // 8 bits per level
+    auto kget = [&](int l) { return (int)((kpack >> (8 * l)) & 255u); };
+    auto kset = [&](int l, int val) { kpack = (kpack & ~(255ull << (8 * l))) | ((unsigned long long)val << (8 * l)); };
+    int l = 0;
+    bool down = true;
+    for (;;) {
+        if (down) {
+            smooth(l, A.a1);
+            const bool rec = l + 1 < A.nlev && A.v > 0;
+            if (rec) {
+                kset(l, 0);
+                residual(l);
+                restrict_zero(l);
+                ++l;
+            } else {
+                smooth(l, A.a2);
+                down = false;
+            }
+        } else {
+            if (l == 0)
+                break;
+            --l;
+            correct(l);
+            kset(l, kget(l) + 1);
+            if (kget(l) < A.v) {
+                residual(l);
+                restrict_zero(l);
+                ++l;
+                down = true;
+            } else {
+                smooth(l, A.a2);
+            }
+        }
+    }
+
+    {
+        const int n0 = A.nx[0] * A.ny[0] * A.nz[0];
+        for (int i = tid; i < n0; i += kThreads)
+            u_out[i] = base[i];
+    }
+}
+
+template <class R> size_t lds_need(int nlev, const int *nx, const int *ny, const int *nz)
+{
+    size_t elems = 0;
+    for (int l = 0; l < nlev; ++l)
+        elems += (size_t)nx[l] * ny[l] * nz[l] * (l + 1 < nlev ? 3 : 2);
+    return elems * sizeof(R);
+}
+
+constexpr size_t kLdsBudget = 150 * 1024; // of the 160 KB of a CU
+
+template <class R>
+mgrt_status bottom(int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull, R *u,
+                   const R *u_in, const R *f, R omega, int a1, int a2, int v, hipStream_t hs)
+{
+    MGRT_REQUIRE(nlev >= 1 && nlev <= kMaxLev, "bottom cycle: %d levels", nlev);
+    MGRT_REQUIRE(v < 256, "bottom cycle: %d coarse solves per level", v);
+    const size_t need = lds_need<R>(nlev, nx, ny, nz);
+    MGRT_REQUIRE(need <= kLdsBudget, "bottom cycle: %zu bytes of LDS needed", need);
+    BottomArgs A;
+    A.nlev = nlev;
+    for (int l = 0; l < nlev; ++l)
+        A.nx[l] = nx[l], A.ny[l] = ny[l], A.nz[l] = nz[l];
+    for (int i = 0; i < 6; ++i)
+        A.face[i] = face[i];
+    A.zfull = zfull, A.a1 = a1, A.a2 = a2, A.v = v;
+    static bool raised = false; // per process and element type: allow more than 64 KB of dynamic LDS
+    if (!raised) {
+        MGRT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bottom_cycle<R>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        raised = true;
+    }
+    k_bottom_cycle<R><<<1, kThreads, need, hs>>>(A, u, u_in, f, omega);
+    MGRT_HIP(hipGetLastError());
+    return MGRT_OK;
+}
+
+} // namespace
+
+namespace mgrt {
+
+size_t bottom_cycle_lds_bytes(int elem_size, int nlev, const int *nx, const int *ny, const int *nz)
+{
+    return elem_size == 4 ? lds_need<float>(nlev, nx, ny, nz) : lds_need<double>(nlev, nx, ny, nz);
+}
+size_t bottom_cycle_lds_budget() { return kLdsBudget; }
+int bottom_cycle_max_levels() { return kMaxLev; }
+
+mgrt_status bottom_cycle(int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull, float *u,
+                         const float *u_in, const float *f, float omega, int a1, int a2, int v, hipStream_t hs)
+{
+    return bottom<float>(nlev, nx, ny, nz, face, zfull, u, u_in, f, omega, a1, a2, v, hs);
+}
+mgrt_status bottom_cycle(int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull, double *u,
+                         const double *u_in, const double *f, double omega, int a1, int a2, int v, hipStream_t hs)
+{
+    return bottom<double>(nlev, nx, ny, nz, face, zfull, u, u_in, f, omega, a1, a2, v, hs);
+}
+
+} // namespace mgrt

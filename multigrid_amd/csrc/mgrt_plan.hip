@@ -29,10 +29,13 @@ struct mgrt_plan {
     // measured at 513^3 the two streaming kernels together are faster than the fused one.
     // MGRT_FUSE_RESIDUAL_RESTRICT=1 in the environment at plan creation turns it on.
     bool fuse_rr = false;
+    // run the coarsest levels as one launch (mgrt_bottom.hip); MGRT_NO_BOTTOM=1 turns it off
+    bool use_bottom = true;
     double *d_norms = nullptr; // device: residual norms of a run
     int norms_cap = 0;
     // cached graph of one iterate() call
     hipGraphExec_t exec = nullptr;
+    int bottom = 1 << 30; // first level of the one-launch bottom, set at the start of every run
     struct Key {
         void *u;
         const void *f;
@@ -85,6 +88,37 @@ template <> struct K<double> {
     static constexpr auto prolong = mgrt_prolong_f64;
 };
 
+// First level from which the rest of the hierarchy runs as one launch, or the level count when
+// none does: 3D, no byte maps from there down, and all arrays of those levels fit in LDS.
+int bottom_from(const mgrt_plan *p)
+{
+    const int n = (int)p->lv.size();
+    if (!p->use_bottom || p->desc.no_fuse || p->desc.dim != 3)
+        return n;
+    int first = n;
+    for (int l = n - 1; l >= 0; --l) {
+        if (p->lv[l].cells || n - l > bottom_cycle_max_levels())
+            break;
+        int nx[16], ny[16], nz[16];
+        for (int m = l; m < n; ++m)
+            nx[m - l] = p->lv[m].g.nx, ny[m - l] = p->lv[m].g.ny, nz[m - l] = p->lv[m].g.nz;
+        if (bottom_cycle_lds_bytes(p->desc.elem_size, n - l, nx, ny, nz) > bottom_cycle_lds_budget())
+            break;
+        first = l;
+    }
+    return first;
+}
+
+template <class R>
+mgrt_status run_bottom(mgrt_plan *p, int l, R *u, const R *u_in, const R *f, R omega, int a1, int a2, int v)
+{
+    const int n = (int)p->lv.size();
+    int nx[16], ny[16], nz[16];
+    for (int m = l; m < n; ++m)
+        nx[m - l] = p->lv[m].g.nx, ny[m - l] = p->lv[m].g.ny, nz[m - l] = p->lv[m].g.nz;
+    return bottom_cycle(n - l, nx, ny, nz, p->lv[l].g.face, p->desc.zfull, u, u_in, f, omega, a1, a2, v, p->stream);
+}
+
 // The fused sweep kernel covers 3D analytic-box levels; everything else smooths in place with
 // the single-colour kernel.
 bool sweepable(const mgrt_plan *p, const mgrt_grid &g) { return !p->desc.no_fuse && g.dim == 3 && g.cells == nullptr; }
@@ -124,6 +158,8 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
 {
     mgrt_plan::Level &L = p->lv[l];
     mgrt_stream s = (mgrt_stream)p->stream;
+    if (l >= p->bottom)
+        return run_bottom<R>(p, l, u, u_is_zero ? nullptr : u, f, omega, a1, a2, v);
     R *cur = u, *alt = (R *)L.work;
     // Number of out-of-place sweeps for the pre- and post-smoother: as few as possible, but an
     // even total so that the result lands in u without a copy.
@@ -178,6 +214,7 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
 
 template <class R> mgrt_status run_cycle(mgrt_plan *p, R *u, const R *f, R omega, int a1, int a2, int v)
 {
+    p->bottom = bottom_from(p);
     if (!p->desc.use_graph)
         return iterate<R>(p, 0, u, f, omega, a1, a2, v);
     const mgrt_plan::Key key{u, f, (double)omega, a1, a2, v};
@@ -283,7 +320,8 @@ mgrt_status mgrt_plan_create(mgrt_plan **plan, const mgrt_plan_desc *d, mgrt_str
     const int nz0 = d->dim == 3 ? d->nz : 1;
     MGRT_REQUIRE(d->nx > 0 && d->ny > 0 && nz0 > 0, "mgrt_plan_create: extents must be positive");
     for (int i = 0; i < 6; ++i)
-        MGRT_REQUIRE(d->face[i] >= 0 && d->face[i] <= 3, "mgrt_plan_create: face[%d] is not a cell class", i);
+        MGRT_REQUIRE(d->face[i] >= 1 && d->face[i] <= 3,
+                     "mgrt_plan_create: face[%d] is not a class a face can have (outer, Dirichlet, Neumann)", i);
 
     mgrt_plan *p = new mgrt_plan;
     p->desc = *d;
@@ -322,6 +360,8 @@ mgrt_status mgrt_plan_create(mgrt_plan **plan, const mgrt_plan_desc *d, mgrt_str
         if (d->dim == 3)
             nz = (nz + 1) / 2;
     }
+    if (const char *e = getenv("MGRT_NO_BOTTOM"))
+        p->use_bottom = e[0] != '1';
     if (const char *e = getenv("MGRT_FUSE_RESIDUAL_RESTRICT"))
         p->fuse_rr = !d->no_fuse && e[0] == '1';
     const size_t w = (size_t)d->elem_size;
@@ -418,6 +458,7 @@ mgrt_status mgrt_plan_fmg(mgrt_plan *p, void *u_out, const void *f, double omega
     if (mgrt_status st = require_init()) return st;
     MGRT_REQUIRE(p && u_out && f, "mgrt_plan_fmg: null argument");
     MGRT_REQUIRE(a1 >= 0 && a2 >= 0 && v >= 0 && iters >= 0, "mgrt_plan_fmg: negative count");
+    p->bottom = bottom_from(p);
     if (p->desc.elem_size == 4)
         return fmg<float>(p, 0, (float *)u_out, (const float *)f, (float)omega, a1, a2, v, iters);
     return fmg<double>(p, 0, (double *)u_out, (const double *)f, omega, a1, a2, v, iters);

@@ -46,7 +46,9 @@ mgrt_status check_grid(const mgrt_grid *g, const char *who)
     MGRT_REQUIRE(g->slab * (long long)g->nz < (1LL << 40), "%s: grid too large", who);
     if (!g->cells)
         for (int i = 0; i < 6; ++i)
-            MGRT_REQUIRE(g->face[i] >= 0 && g->face[i] <= 3, "%s: face[%d] = %d is not a cell class", who, i,
+            // an inner cell on a face would reach outside the arrays with its stencil
+            MGRT_REQUIRE(g->face[i] >= 1 && g->face[i] <= 3,
+                         "%s: face[%d] = %d is not a class a face can have (outer, Dirichlet, Neumann)", who, i,
                          g->face[i]);
     return MGRT_OK;
 }

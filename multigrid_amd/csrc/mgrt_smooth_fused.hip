@@ -396,6 +396,10 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
             case 6: return launch<R, 2, 2, 12, 6>(g, out, in, f, omega, zcount, hs);
             case 7: return launch<R, 2, 4, 12, 3>(g, out, in, f, omega, zcount, hs);
             case 8: return launch<R, 2, 6, 6, 3>(g, out, in, f, omega, zcount, hs);
+            case 9: return launch<R, 2, 4, 4, 3>(g, out, in, f, omega, zcount, hs);
+            case 10: return launch<R, 2, 6, 4, 3>(g, out, in, f, omega, zcount, hs);
+            case 11: return launch<R, 2, 4, 3, 3>(g, out, in, f, omega, zcount, hs);
+            case 12: return launch<R, 2, 8, 2, 2>(g, out, in, f, omega, zcount, hs);
             }
         }
         if (sizeof(R) == 4 && iters == 1) {
@@ -406,6 +410,10 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
             case 4: return launch<R, 1, 8, 4, 2>(g, out, in, f, omega, zcount, hs);
             case 5: return launch<R, 1, 4, 16, 4>(g, out, in, f, omega, zcount, hs);
             case 6: return launch<R, 1, 8, 8, 2>(g, out, in, f, omega, zcount, hs);
+            case 9: return launch<R, 1, 2, 4, 4>(g, out, in, f, omega, zcount, hs);
+            case 10: return launch<R, 1, 4, 2, 4>(g, out, in, f, omega, zcount, hs);
+            case 11: return launch<R, 1, 4, 4, 4>(g, out, in, f, omega, zcount, hs);
+            case 12: return launch<R, 1, 2, 6, 4>(g, out, in, f, omega, zcount, hs);
             }
         }
     }
