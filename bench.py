@@ -38,16 +38,18 @@ def make_problem(n, device):
     return f.contiguous(), sol.contiguous()
 
 
-def pmc_traffic(kernel, n, template=""):
+def pmc_traffic(kernel, n, fields):
     """HBM bytes per launch of `kernel` at n^3 from the committed counter passes (profiles/
     pmc_traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE and WRITE_SIZE
-    rocprofv3 runs).  None when no pass for this size is on file: counters cannot be read from
-    inside the timed process."""
+    rocprofv3 runs).  `fields` maps positions in the kernel's template argument list to the values
+    that pick the variant timed here.  None when no pass for this size is on file: counters cannot
+    be read from inside the timed process."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             for row in json.load(fh):
+                args = [a.strip() for a in row["template"].split(",")]
                 if row["kernel"] == kernel and row["n"] == n and row["dtype"] == "f32" and \
-                        row["template"].replace(" ", "").startswith(template):
+                        all(i < len(args) and args[i] == v for i, v in fields.items()):
                     return row["traffic_bytes"]
     except (OSError, ValueError, KeyError):
         pass
@@ -190,7 +192,8 @@ def main():
         dof = float(n) ** 3
         alg_bytes = 3.0 * dof * 4  # sweep: read u, read f, write the smoothed field, once each
         achieved = alg_bytes / t_sweep / 1e9
-        traffic = pmc_traffic("k_smooth3d_fused", n, "float,2,")  # <R, ITERS = 2, ...>: the variant timed here
+        # <R, ITERS, SR, NW, PD, OMEGA1, RES>: two iterations, omega == 1, no residual pass
+        traffic = pmc_traffic("k_smooth3d_fused", n, {0: "float", 1: "2", 5: "true", 6: "false"})
         # algorithmic bytes of a whole unfused V(2,2) cycle: 22 N w + 3 Nc w per level, 16 N w coarsest
         sizes, m = [], n
         while True:

@@ -95,6 +95,18 @@ def main():
         if depth2:
             loop_lines.append((in_asm, line))
     flush()
+    # A kernel that spills would move prefetch registers through scratch memory behind the counted
+    # waits: the metadata must show no private segment for any of these kernels.
+    name = None
+    for line in text:
+        m = re.match(r"\s+\.name:\s+(\S*k_smooth3d_fused\S*)", line)
+        if m:
+            name = m.group(1)
+        m = re.match(r"\s+\.private_segment_fixed_size:\s+(\d+)", line)
+        if m:
+            if name and int(m.group(1)) > 0:
+                bad.append((name, "uses %s bytes of scratch memory per lane" % m.group(1)))
+            name = None
     if nk == 0 or loops == 0:
         print("check_hidden_loads: found %d kernels, %d inner loops -- the audit did not run" % (nk, loops))
         return 1
