@@ -125,6 +125,7 @@ def main():
     u = torch.zeros_like(f)
     stream = torch.cuda.Stream()
     sync = torch.zeros(1, device=dev)
+    torch.cuda.synchronize()  # the fields were produced on the default stream
 
     def barrier():
         torch.cuda.synchronize()

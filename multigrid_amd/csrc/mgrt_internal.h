@@ -39,7 +39,7 @@ mgrt_status require_init();
 // Argument validation shared by the kernel launchers.
 mgrt_status check_grid(const mgrt_grid *g, const char *who);
 
-constexpr int kMaxPartials = 1 << 16;
+constexpr int kMaxPartials = 1 << 20;
 
 // Levels of at most about 300^2 columns are bound by the latency of a z step of the fused smoother,
 // not by bandwidth: they get narrower strips, and carrying the residual pass along does not pay.

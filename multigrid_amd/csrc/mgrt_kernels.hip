@@ -931,7 +931,10 @@ mgrt_status residual(const mgrt_grid *g, R *r, const R *u, const R *f, int zero_
     constexpr int ZC = 16;
     const long long nthreads = g->dim == 3 ? (long long)((g->nx + 16 / (int)sizeof(R) - 1) / (16 / (int)sizeof(R))) * (yhi - ylo) : n;
     const unsigned nbxy = blocks_for(nthreads, 256);
-    const int zc3 = g->dim == 3 ? z_chunk(nbxy, g->nz, ZC) : 1;
+    int zc3 = g->dim == 3 ? z_chunk(nbxy, g->nz, ZC) : 1;
+    // with the norm every block leaves a partial sum: longer chunks keep their number within the scratch
+    while (norm2 && g->dim == 3 && zc3 < g->nz && (size_t)nbxy * blocks_for(g->nz, zc3) > runtime().partials_cap)
+        zc3 *= 2;
     dim3 grid(nbxy * (g->dim == 3 ? blocks_for(g->nz, zc3) : 1));
     const int nparts = (int)grid.x;
     MGRT_REQUIRE(!norm2 || (size_t)nparts <= runtime().partials_cap, "mgrt_residual: grid too large for the fused norm");

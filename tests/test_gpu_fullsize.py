@@ -1,0 +1,102 @@
+"""The configurations the benchmark is quoted on, at full size, through properties that need no
+CPU reference: the default plan (fused sweeps, residual pass in the sweep, one-launch bottom) must
+equal the unfused plan bit for bit -- the unfused kernels are the ones checked against the oracle
+at small sizes --, the residual must fall at the known multigrid rate, and cells the reference never
+writes must keep their values."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def problem(shape, dtype, dev):
+    """sin products sampled like discretize_func (functionhandler.cpp:64-84): f*h*h inside,
+    the exact solution on the faces."""
+    import math
+    import torch
+    axes = [torch.arange(n, device=dev, dtype=torch.float64) / (n - 1) for n in shape]
+    s = [torch.sin(math.pi * a) for a in axes]
+    if len(shape) == 3:
+        sol = s[0][:, None, None] * s[1][None, :, None] * s[2][None, None, :]
+        lap = -3.0 * math.pi ** 2
+    else:
+        sol = s[0][:, None] * s[1][None, :]
+        lap = -2.0 * math.pi ** 2
+    h = 1.0 / (shape[-1] - 1)
+    f = (lap * sol * h * h).to(dtype)
+    sol = sol.to(dtype)
+    for d in range(len(shape)):
+        idx = [slice(None)] * len(shape)
+        for e in (0, -1):
+            idx[d] = e
+            f[tuple(idx)] = sol[tuple(idx)]
+    return f.contiguous()
+
+
+def run(shape, dtype, dev, cycles, faces=None, **kw):
+    import torch
+    from multigrid_amd import _lib as L
+    f = problem(shape, dtype, dev)
+    u = torch.zeros_like(f)
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())  # f and u are produced on the current stream
+    with torch.cuda.stream(stream):
+        plan = L.Plan(shape, dtype, zfull=True, **({"faces": faces} if faces else {}), **kw)
+        hist = plan.vcycle(u, f, 1.0, 2, 2, 1, cycles, history=True)
+        plan.close()
+    torch.cuda.synchronize()
+    return u, f, hist
+
+
+def test_513_cubed_f32_fused_equals_unfused(dev):
+    """BASELINE config 4 on one GPU: 3D 513^3 Dirichlet, V(2,2)."""
+    import torch
+    shape = (513, 513, 513)
+    u1, f, h1 = run(shape, torch.float32, dev, 2, use_graph=True)
+    u2, _, h2 = run(shape, torch.float32, dev, 2, no_fuse=True)
+    assert torch.equal(u1.view(torch.int32), u2.view(torch.int32))
+    assert h1[0] == h2[0] and all(abs(a - b) <= 1e-9 * b for a, b in zip(h1, h2))
+    assert h1[1] < 0.25 * h1[0] and h1[2] < 0.25 * h1[1]          # V(2,2) contracts by ~0.12 per cycle here
+    assert torch.equal(u1[0], f[0]) and torch.equal(u1[:, :, -1], f[:, :, -1])  # Dirichlet faces hold f
+
+
+def test_257_cubed_neumann_faces_are_frozen(dev):
+    """BASELINE config 3: 3D 257^3 with Neumann faces, which the reference never updates, and the
+    Dirichlet variant of the same grid."""
+    import torch
+    from multigrid_amd import _lib as L
+    shape = (257, 257, 257)
+    u1, f, h1 = run(shape, torch.float32, dev, 2, faces=(L.NEUMANN,) * 6, use_graph=True)
+    u2, _, h2 = run(shape, torch.float32, dev, 2, faces=(L.NEUMANN,) * 6, no_fuse=True)
+    assert torch.equal(u1.view(torch.int32), u2.view(torch.int32))
+    for d in range(3):
+        for e in (0, -1):
+            idx = [slice(None)] * 3
+            idx[d] = e
+            assert not u1[tuple(idx)].any()          # started at 0 and must still be 0
+    ud, fd, hd = run(shape, torch.float32, dev, 3, use_graph=True)
+    assert hd[3] < 0.02 * hd[0]
+
+
+def test_1025_cubed_f64_one_cycle(dev):
+    """BASELINE config 5 on one GPU: 3D 1025^3 in double."""
+    import torch
+    shape = (1025, 1025, 1025)
+    u1, f, h1 = run(shape, torch.float64, dev, 1, use_graph=True)
+    ref = float(u1.double().abs().max())
+    assert 0.3 < ref < 1.2 and h1[1] < 0.25 * h1[0]
+    del f
+    u2, _, h2 = run(shape, torch.float64, dev, 1, no_fuse=True)
+    assert torch.equal(u1.view(torch.int64), u2.view(torch.int64))
+
+
+def test_4097_squared_f32_mixed_faces(dev):
+    """BASELINE config 2: 2D 4097^2, Dirichlet on the x faces, Neumann (frozen) on the y faces."""
+    import torch
+    from multigrid_amd import _lib as L
+    shape = (4097, 4097)
+    faces = (L.DIRICHLET, L.DIRICHLET, L.NEUMANN, L.NEUMANN, L.DIRICHLET, L.DIRICHLET)
+    u, f, h = run(shape, torch.float32, dev, 3, faces=faces, use_graph=True)
+    assert torch.equal(u[:, 0], f[:, 0]) and torch.equal(u[:, -1], f[:, -1])   # x faces: Dirichlet, u = f
+    assert not u[0, 1:-1].any() and not u[-1, 1:-1].any()                      # y faces: never written
+    assert h[-1] < h[0] and np.isfinite(h).all()

@@ -230,6 +230,7 @@ def test_cycle_on_wide_planes_matches_oracle(dev, mgo, v):
     mgo.mg(ref, f, np.float32(0.9), 2, 2, v, 2, True)
     du, df = to_dev(u, dev), to_dev(f, dev)
     stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(stream):
         plan = L.Plan(shape, torch.float32, zfull=True, use_graph=True)
         plan.vcycle(du, df, 0.9, 2, 2, v, 2)
@@ -282,6 +283,7 @@ def run_plan(dev, g, use_graph=False, no_fuse=False):
     tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}[f.dtype]
     zfull, a1, a2, v, cycles = (int(g[k]) for k in ("zfull", "a1", "a2", "v", "cycles"))
     stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(stream):
         df = to_dev(f, dev)
         plan = L.Plan(shape, tdt, zfull=bool(zfull), use_graph=use_graph, no_fuse=no_fuse)
