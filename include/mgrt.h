@@ -105,8 +105,8 @@ mgrt_status mgrt_box_cells_host(int dim, int nx, int ny, int nz, const int face[
     mgrt_status mgrt_smooth##S(const mgrt_grid *g, R *u, const R *f, R omega, int iters,           \
                                int zcount, mgrt_stream s);                                         \
     /* One fused z-march: out = S^iters(in) for iters in {1,2}, every field element read once and  \
-       written once; same results as 2*iters calls of mgrt_smooth_pass on a copy of `in`.  3D      \
-       analytic-box grids only (MGRT_E_UNSUPPORTED otherwise: use the pass kernel).  out must not  \
+       written once; same results as 2*iters calls of mgrt_smooth_pass on a copy of `in`.          \
+       Analytic-box grids only (MGRT_E_UNSUPPORTED otherwise: use the pass kernel).  out must not  \
        alias in.  in == NULL stands for a field of zeros (the cleared coarse unknown of              \
        multigridsolver3D.cpp:59).  Replaces the launch loop of smoother_iterate                      \
        (multigridsolver3D.cpp:124-131). */                                                          \

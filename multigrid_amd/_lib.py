@@ -177,12 +177,12 @@ def smooth(g, u, f, omega, iters, zcount=None, stream=None):
 
 
 def smooth_sweep(g, out, inp, f, omega, iters, zcount=None, stream=None):
-    check(_fn("smooth_sweep", inp)(C.byref(g), _p(out), _p(inp), _p(f), omega, iters,
+    check(_fn("smooth_sweep", f)(C.byref(g), _p(out), _p(inp), _p(f), omega, iters,
                                    g.nz if zcount is None else zcount, _stream(stream)))
 
 
 def smooth_sweep_residual(g, out, r, inp, f, omega, iters, zcount=None, stream=None):
-    check(_fn("smooth_sweep_residual", inp)(C.byref(g), _p(out), _p(r), _p(inp), _p(f), omega, iters,
+    check(_fn("smooth_sweep_residual", f)(C.byref(g), _p(out), _p(r), _p(inp), _p(f), omega, iters,
                                             g.nz if zcount is None else zcount, _stream(stream)))
 
 

@@ -65,6 +65,12 @@ mgrt_status bottom_cycle(int nlev, const int *nx, const int *ny, const int *nz, 
 mgrt_status bottom_cycle(int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull, double *u,
                          const double *u_in, const double *f, double omega, int a1, int a2, int v, hipStream_t hs);
 
+// out = S^iters(in) on a 2D analytic-box grid, iters 1 or 2 (mgrt_smooth2d.hip); in may be null
+mgrt_status smooth_sweep_2d(const mgrt_grid *g, float *out, const float *in, const float *f, float omega, int iters,
+                            hipStream_t hs);
+mgrt_status smooth_sweep_2d(const mgrt_grid *g, double *out, const double *in, const double *f, double omega, int iters,
+                            hipStream_t hs);
+
 } // namespace mgrt
 
 #endif

@@ -119,9 +119,9 @@ mgrt_status run_bottom(mgrt_plan *p, int l, R *u, const R *u_in, const R *f, R o
     return bottom_cycle(n - l, nx, ny, nz, p->lv[l].g.face, p->desc.zfull, u, u_in, f, omega, a1, a2, v, p->stream);
 }
 
-// The fused sweep kernel covers 3D analytic-box levels; everything else smooths in place with
+// The fused sweep kernels cover analytic-box levels; levels with a byte map smooth in place with
 // the single-colour kernel.
-bool sweepable(const mgrt_plan *p, const mgrt_grid &g) { return !p->desc.no_fuse && g.dim == 3 && g.cells == nullptr; }
+bool sweepable(const mgrt_plan *p, const mgrt_grid &g) { return !p->desc.no_fuse && g.cells == nullptr; }
 
 // `a` smoothing iterations on *cur, as `nsweeps` out-of-place fused sweeps that ping-pong between
 // *cur and *alt (nsweeps between ceil(a/2) and a), or in place when nsweeps == 0.  With `res`, the
@@ -178,7 +178,7 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
         u_is_zero = false;
     }
     // On bandwidth-bound levels the last pre-smoothing sweep carries the residual pass along.
-    const bool res_in_sweep = n1 > 0 && v > 0 && recurses(L.g) && !latency_bound_level(L.g) && !p->fuse_rr;
+    const bool res_in_sweep = L.g.dim == 3 && n1 > 0 && v > 0 && recurses(L.g) && !latency_bound_level(L.g) && !p->fuse_rr;
     if (a1 > 0)
         if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a1, n1, res_in_sweep ? (R *)L.r : nullptr, u_is_zero))
             return st;
@@ -370,7 +370,7 @@ mgrt_status mgrt_plan_create(mgrt_plan **plan, const mgrt_plan_desc *d, mgrt_str
         hipError_t e = hipSuccess;
         if (l + 1 < p->lv.size())
             e = hipMalloc(&L.r, L.n * w);
-        if (e == hipSuccess && d->dim == 3 && !d->no_fuse)
+        if (e == hipSuccess && !d->no_fuse)
             e = hipMalloc(&L.work, L.n * w);
         if (e == hipSuccess && l > 0)
             e = hipMalloc(&L.rhs, L.n * w);

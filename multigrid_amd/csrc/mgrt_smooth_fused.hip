@@ -374,13 +374,16 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
     MGRT_REQUIRE(!res || (res != out && res != in && res != f), "mgrt_smooth_sweep_residual: r must not alias another field");
     MGRT_REQUIRE(zcount >= 0 && zcount <= g->nz, "mgrt_smooth_sweep: zcount %d outside [0,%d]", zcount, g->nz);
     MGRT_REQUIRE(g->slab < (1LL << 30), "mgrt_smooth_sweep: plane too large for 32-bit in-plane offsets");
-    if (g->dim != 3)
-        return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep: 3D grids only");
     if (g->cells)
         return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep: byte cell maps are not supported, use mgrt_smooth_pass");
     if (iters != 1 && iters != 2)
         return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep: iters must be 1 or 2, got %d", iters);
     hipStream_t hs = (hipStream_t)s;
+    if (g->dim != 3) {
+        if (res)
+            return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep_residual: 3D grids only");
+        return smooth_sweep_2d(g, out, in, f, omega, iters, hs);
+    }
     using C = Cfg<R>;
 #ifdef MGRT_TUNE
     // development only: pick a tile shape at run time

@@ -239,6 +239,42 @@ def test_cycle_on_wide_planes_matches_oracle(dev, mgo, v):
     assert bits_equal(du.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", [(5, 5), (9, 17), (33, 65), (64, 70), (130, 67), (257, 129)],
+                         ids=lambda s: "x".join(map(str, s[::-1])))
+def test_fused_sweep_2d_matches_oracle(dev, mgo, dt, shape):
+    """2D: out = S^iters(in) from LDS tiles against 2*iters single-colour passes of the oracle,
+    whole grids and a y-slab, and the zero-input form."""
+    import torch
+    from multigrid_amd import _lib as L
+    rng = np.random.default_rng(abs(hash((shape, dt.__name__, "sweep2d"))) % 2**32)
+    for faces in ((2,) * 6, (2, 3, 3, 2, 2, 2), (3, 2, 1, 2, 2, 2)):
+        cell = mgo.box_cells(shape, faces)
+        g = L.grid(shape, faces=faces)
+        u = rng.standard_normal(shape).astype(dt)
+        f = rng.standard_normal(shape).astype(dt)
+        for iters, omega in ((1, 1.0), (2, 0.8)):
+            ref = u.copy()
+            zref = np.zeros_like(u)
+            for _ in range(iters):
+                for odd in (0, 1):
+                    mgo.smooth_pass(cell, ref, f, dt(omega), odd)
+                    mgo.smooth_pass(cell, zref, f, dt(omega), odd)
+            du, df = to_dev(u, dev), to_dev(f, dev)
+            out = torch.full_like(du, 3.0)
+            L.smooth_sweep(g, out, du, df, omega, iters)
+            assert bits_equal(out.cpu().numpy(), ref), (shape, faces, iters)
+            L.smooth_sweep(g, out, None, df, omega, iters)
+            assert bits_equal(out.cpu().numpy(), zref), (shape, faces, iters, "zero input")
+            if shape[0] > 20:
+                h, y0, y1 = 2 * iters, 7, shape[0] - 6
+                us, fs = du[y0 - h:y1 + h].contiguous(), df[y0 - h:y1 + h].contiguous()
+                gs = L.grid(tuple(us.shape), faces=faces, y0=y0 - h, gny=shape[0])
+                outs = torch.empty_like(us)
+                L.smooth_sweep(gs, outs, us, fs, omega, iters)
+                assert bits_equal(outs[h:-h].cpu().numpy(), ref[y0:y1]), (shape, faces, iters, "slab")
+
+
 def test_fused_sweep_on_a_slab(dev):
     """Rows of a y-slab (odd global offset, so the colours are shifted) equal the whole-grid rows
     wherever the halo of 2*iters rows was available."""
