@@ -1,4 +1,4 @@
-// mgrt_bottom.hip -- the coarsest levels of a 3D cycle in one launch.
+// mgrt_bottom.hip -- the coarsest levels of a cycle in one launch.
 //
 // From about 17^3 points down a level is a handful of microseconds of work, and a V(2,2) cycle
 // spends six launches on it: the cycle is then bound by launch latency.  This kernel runs
@@ -7,7 +7,8 @@
 // 56-104; a thread owns a column and marches z, as k_smooth3d_pass does), residual (mg_1.cl:46-53,
 // 111-133), restriction (mg_1.cl:146-190) and correction (mg_1.cl:200-233), separated by
 // workgroup barriers.  Expressions and operand order are those of the per-step kernels in
-// mgrt_kernels.hip, so the values are the same bit for bit.  Analytic box domains only.
+// mgrt_kernels.hip, so the values are the same bit for bit.  The 2D twins (mg_0.cl) run as grids of
+// one plane with their own expressions.  Analytic box domains only.
 #include "mgrt_internal.h"
 
 using namespace mgrt;
@@ -17,6 +18,7 @@ namespace {
 constexpr int kMaxLev = 8, kThreads = 1024;
 
 struct BottomArgs {
+    int dim;
     int nlev;
     int nx[kMaxLev], ny[kMaxLev], nz[kMaxLev];
     int face[6];
@@ -27,9 +29,16 @@ struct Lvl {
     int nx, ny, nz, p, s, n, zcount;
 };
 
-__device__ __forceinline__ int box_class(const Lvl &L, const int (&face)[6], int x, int y, int z)
+template <int DIM> __device__ __forceinline__ int box_class(const Lvl &L, const int (&face)[6], int x, int y, int z)
 {
-    // same order as cell_class<3, false>
+    // same order as cell_class<DIM, false>
+    if (DIM == 2) {
+        if (x == 0) return face[0];
+        if (x == L.nx - 1) return face[1];
+        if (y == 0) return face[2];
+        if (y == L.ny - 1) return face[3];
+        return MGRT_CELL_INNER;
+    }
     if (y == 0) return face[2];
     if (y == L.ny - 1) return face[3];
     if (x == 0) return face[0];
@@ -46,7 +55,7 @@ template <class R> __device__ __forceinline__ R dot4b(R a0, R a1, R a2, R a3, R 
     return a0 * b0 + a1 * b1 + a2 * b2 + a3 * b3;
 }
 
-template <class R>
+template <class R, int DIM>
 __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_out, const R *u_in, const R *f_in, R omega)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -58,7 +67,7 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
         Lvl L;
         L.nx = A.nx[l], L.ny = A.ny[l], L.nz = A.nz[l];
         L.p = L.nx, L.s = L.nx * L.ny, L.n = L.s * L.nz;
-        L.zcount = A.zfull ? L.nz : L.nz / 2 + L.nz % 2; // multigridsolver3D.cpp:121
+        L.zcount = DIM == 2 || A.zfull ? L.nz : L.nz / 2 + L.nz % 2; // multigridsolver3D.cpp:121
         return L;
     };
     auto u_of = [&](int l) {
@@ -92,6 +101,17 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
                 const int y = idx / hx, x = 2 * (idx % hx) + ((odd + y) & 1);
                 if (x >= L.nx)
                     continue;
+                if (DIM == 2) { // true red-black point update, mg_0.cl:29-40,52-98
+                    const int b = x + L.p * y;
+                    const int t = box_class<2>(L, face, x, y, 0);
+                    if (t == MGRT_CELL_INNER) {
+                        const R val = 0.25 * (u[b + 1] + u[b - 1] + u[b + L.p] + u[b - L.p] - f[b]);
+                        u[b] = val * omega + (1.0 - omega) * u[b];
+                    } else if (t == MGRT_CELL_DIRICHLET) {
+                        u[b] = f[b];
+                    }
+                    continue;
+                }
                 // class of the column where it does not depend on z, else -1
                 const int lat = y == 0 ? face[2] : y == L.ny - 1 ? face[3] : x == 0 ? face[0] : x == L.nx - 1 ? face[1] : -1;
                 const int col = x + L.p * y;
@@ -149,10 +169,11 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
         R *r = u_of(l) + 2 * L.n;
         for (int i = tid; i < L.n; i += kThreads) {
             const int x = i % L.nx, y = (i / L.nx) % L.ny, z = i / L.s;
-            const int t = box_class(L, face, x, y, z);
+            const int t = box_class<DIM>(L, face, x, y, z);
             R v = 0;
             if (t == MGRT_CELL_INNER)
-                v = f[i] - (u[i + 1] + u[i - 1] + u[i + L.p] + u[i - L.p] + u[i + L.s] + u[i - L.s] - 6 * u[i]);
+                v = DIM == 3 ? f[i] - (u[i + 1] + u[i - 1] + u[i + L.p] + u[i - L.p] + u[i + L.s] + u[i - L.s] - 6 * u[i])
+                             : f[i] - (u[i + 1] + u[i - 1] + u[i + L.p] + u[i - L.p] - 4 * u[i]);
             else if (t == MGRT_CELL_DIRICHLET)
                 v = f[i] - u[i];
             r[i] = v;
@@ -168,28 +189,33 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
         const int p = Lf.p, s = Lf.s;
         for (int d = tid; d < Lc.n; d += kThreads) {
             const int i = d % Lc.nx, j = (d / Lc.nx) % Lc.ny, k = d / Lc.s;
-            const int x = 2 * i, y = 2 * j, z = 2 * k;
+            const int x = 2 * i, y = 2 * j, z = DIM == 3 ? 2 * k : 0;
             const R *c = rf + x + p * y + s * z;
-            const bool on_face = x == 0 || x == Lf.nx - 1 || y == 0 || y == Lf.ny - 1 || z == 0 || z == Lf.nz - 1;
-            bool border = on_face || border_class(box_class(Lf, face, x, y, z));
+            const bool on_face = x == 0 || x == Lf.nx - 1 || y == 0 || y == Lf.ny - 1 ||
+                                 (DIM == 3 && (z == 0 || z == Lf.nz - 1));
+            bool border = on_face || border_class(box_class<DIM>(Lf, face, x, y, z));
             if (!border) {
-                border = border_class(box_class(Lf, face, x + 1, y, z)) || border_class(box_class(Lf, face, x, y + 1, z)) ||
-                         border_class(box_class(Lf, face, x + 1, y + 1, z));
-                if (!border)
-                    border = border_class(box_class(Lf, face, x, y, z + 1)) ||
-                             border_class(box_class(Lf, face, x + 1, y, z + 1)) ||
-                             border_class(box_class(Lf, face, x, y + 1, z + 1)) ||
-                             border_class(box_class(Lf, face, x + 1, y + 1, z + 1));
+                border = border_class(box_class<DIM>(Lf, face, x + 1, y, z)) ||
+                         border_class(box_class<DIM>(Lf, face, x, y + 1, z)) ||
+                         border_class(box_class<DIM>(Lf, face, x + 1, y + 1, z));
+                if (DIM == 3 && !border)
+                    border = border_class(box_class<DIM>(Lf, face, x, y, z + 1)) ||
+                             border_class(box_class<DIM>(Lf, face, x + 1, y, z + 1)) ||
+                             border_class(box_class<DIM>(Lf, face, x, y + 1, z + 1)) ||
+                             border_class(box_class<DIM>(Lf, face, x + 1, y + 1, z + 1));
             }
             R val;
             if (border) {
                 val = c[0];
-            } else {
+            } else if (DIM == 3) {
                 val = 1.0 / 64.0 * (c[s + p + 1] + c[s + p - 1] + c[s - p + 1] + c[s - p - 1] + c[-s + p + 1] +
                                     c[-s + p - 1] + c[-s - p + 1] + c[-s - p - 1]) +
                       1.0 / 32.0 * (c[p + 1] + c[p - 1] + c[-p + 1] + c[-p - 1] + c[-s + p] + c[-s - p] + c[-s + 1] +
                                     c[-s - 1] + c[s + p] + c[s - p] + c[s + 1] + c[s - 1]) +
                       1.0 / 16.0 * (c[p] + c[-p] + c[1] + c[-1] + c[s] + c[-s]) + 1.0 / 8.0 * (c[0]);
+            } else {
+                val = 1.0 / 16.0 * (c[-p - 1] + c[-p + 1] + c[p - 1] + c[p + 1]) +
+                      1.0 / 8.0 * (c[-p] + c[1] + c[-1] + c[p]) + 1.0 / 4.0 * (c[0]);
             }
             rc[d] = val;
             e[d] = 0;
@@ -211,9 +237,9 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
             const int ck1 = ck + 1 < Lc.nz ? ck + 1 : ck;
             const R *e0 = e + cs * ck, *e1 = e + cs * ck1;
             R val;
-            if (border_class(box_class(Lf, face, x, y, z))) {
+            if (border_class(box_class<DIM>(Lf, face, x, y, z))) {
                 val = e0[ci + cp * cj];
-            } else {
+            } else if (DIM == 3) {
                 const R wu = 0.5 * (x % 2), ww = 0.5 * (y % 2), wv = 0.5 * (z % 2);
                 const R n10 = (1.0 - wu) * (1.0 - ww) * (1.0 - wv), n11 = (1.0 - ww) * wu * (1.0 - wv),
                         n12 = (1.0 - wu) * ww * (1.0 - wv), n13 = ww * wu * (1.0 - wv);
@@ -223,6 +249,10 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
                                n13) +
                       dot4b<R>(e1[ci + cp * cj], e1[ci1 + cp * cj], e1[ci + cp * cj1], e1[ci1 + cp * cj1], n20, n21, n22,
                                n23);
+            } else { // mg_0.cl:167-194
+                const R wu = 0.5 * (x % 2), ww = 0.5 * (y % 2);
+                const R n0 = (1.0 - wu) * (1.0 - ww), n1 = (1.0 - ww) * wu, n2 = (1.0 - wu) * ww, n3 = ww * wu;
+                val = dot4b<R>(e0[ci + cp * cj], e0[ci1 + cp * cj], e0[ci + cp * cj1], e0[ci1 + cp * cj1], n0, n1, n2, n3);
             }
             u[d] = u[d] + val * 4;
         }
@@ -284,7 +314,7 @@ template <class R> size_t lds_need(int nlev, const int *nx, const int *ny, const
 constexpr size_t kLdsBudget = 150 * 1024; // of the 160 KB of a CU
 
 template <class R>
-mgrt_status bottom(int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull, R *u,
+mgrt_status bottom(int dim, int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull, R *u,
                    const R *u_in, const R *f, R omega, int a1, int a2, int v, hipStream_t hs)
 {
     MGRT_REQUIRE(nlev >= 1 && nlev <= kMaxLev, "bottom cycle: %d levels", nlev);
@@ -292,6 +322,7 @@ mgrt_status bottom(int nlev, const int *nx, const int *ny, const int *nz, const 
     const size_t need = lds_need<R>(nlev, nx, ny, nz);
     MGRT_REQUIRE(need <= kLdsBudget, "bottom cycle: %zu bytes of LDS needed", need);
     BottomArgs A;
+    A.dim = dim;
     A.nlev = nlev;
     for (int l = 0; l < nlev; ++l)
         A.nx[l] = nx[l], A.ny[l] = ny[l], A.nz[l] = nz[l];
@@ -300,11 +331,16 @@ mgrt_status bottom(int nlev, const int *nx, const int *ny, const int *nz, const 
     A.zfull = zfull, A.a1 = a1, A.a2 = a2, A.v = v;
     static bool raised = false; // per process and element type: allow more than 64 KB of dynamic LDS
     if (!raised) {
-        MGRT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bottom_cycle<R>),
+        MGRT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bottom_cycle<R, 3>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        MGRT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bottom_cycle<R, 2>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
         raised = true;
     }
-    k_bottom_cycle<R><<<1, kThreads, need, hs>>>(A, u, u_in, f, omega);
+    if (dim == 3)
+        k_bottom_cycle<R, 3><<<1, kThreads, need, hs>>>(A, u, u_in, f, omega);
+    else
+        k_bottom_cycle<R, 2><<<1, kThreads, need, hs>>>(A, u, u_in, f, omega);
     MGRT_HIP(hipGetLastError());
     return MGRT_OK;
 }
@@ -320,15 +356,16 @@ size_t bottom_cycle_lds_bytes(int elem_size, int nlev, const int *nx, const int 
 size_t bottom_cycle_lds_budget() { return kLdsBudget; }
 int bottom_cycle_max_levels() { return kMaxLev; }
 
-mgrt_status bottom_cycle(int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull, float *u,
-                         const float *u_in, const float *f, float omega, int a1, int a2, int v, hipStream_t hs)
+mgrt_status bottom_cycle(int dim, int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull,
+                         float *u, const float *u_in, const float *f, float omega, int a1, int a2, int v, hipStream_t hs)
 {
-    return bottom<float>(nlev, nx, ny, nz, face, zfull, u, u_in, f, omega, a1, a2, v, hs);
+    return bottom<float>(dim, nlev, nx, ny, nz, face, zfull, u, u_in, f, omega, a1, a2, v, hs);
 }
-mgrt_status bottom_cycle(int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull, double *u,
-                         const double *u_in, const double *f, double omega, int a1, int a2, int v, hipStream_t hs)
+mgrt_status bottom_cycle(int dim, int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull,
+                         double *u, const double *u_in, const double *f, double omega, int a1, int a2, int v,
+                         hipStream_t hs)
 {
-    return bottom<double>(nlev, nx, ny, nz, face, zfull, u, u_in, f, omega, a1, a2, v, hs);
+    return bottom<double>(dim, nlev, nx, ny, nz, face, zfull, u, u_in, f, omega, a1, a2, v, hs);
 }
 
 } // namespace mgrt

@@ -54,16 +54,17 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nb)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
 }
 
-// The coarsest levels of a 3D box hierarchy as one launch with every level in LDS
+// The coarsest levels of a 2D or 3D box hierarchy as one launch with every level in LDS
 // (mgrt_bottom.hip): iterate(u, f, omega, a1, a2, v) on dense arrays of nx[0]*ny[0]*nz[0] elements,
 // level l having extents nx[l], ny[l], nz[l].  u_in == nullptr: start from zeros.  u may alias u_in.
 size_t bottom_cycle_lds_bytes(int elem_size, int nlev, const int *nx, const int *ny, const int *nz);
 size_t bottom_cycle_lds_budget();
 int bottom_cycle_max_levels();
-mgrt_status bottom_cycle(int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull, float *u,
-                         const float *u_in, const float *f, float omega, int a1, int a2, int v, hipStream_t hs);
-mgrt_status bottom_cycle(int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull, double *u,
-                         const double *u_in, const double *f, double omega, int a1, int a2, int v, hipStream_t hs);
+mgrt_status bottom_cycle(int dim, int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull,
+                         float *u, const float *u_in, const float *f, float omega, int a1, int a2, int v, hipStream_t hs);
+mgrt_status bottom_cycle(int dim, int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull,
+                         double *u, const double *u_in, const double *f, double omega, int a1, int a2, int v,
+                         hipStream_t hs);
 
 // out = S^iters(in) on a 2D analytic-box grid, iters 1 or 2 (mgrt_smooth2d.hip); in may be null
 mgrt_status smooth_sweep_2d(const mgrt_grid *g, float *out, const float *in, const float *f, float omega, int iters,

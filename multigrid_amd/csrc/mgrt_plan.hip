@@ -89,11 +89,11 @@ template <> struct K<double> {
 };
 
 // First level from which the rest of the hierarchy runs as one launch, or the level count when
-// none does: 3D, no byte maps from there down, and all arrays of those levels fit in LDS.
+// none does: no byte maps from there down, and all arrays of those levels fit in LDS.
 int bottom_from(const mgrt_plan *p)
 {
     const int n = (int)p->lv.size();
-    if (!p->use_bottom || p->desc.no_fuse || p->desc.dim != 3)
+    if (!p->use_bottom || p->desc.no_fuse)
         return n;
     int first = n;
     for (int l = n - 1; l >= 0; --l) {
@@ -116,7 +116,7 @@ mgrt_status run_bottom(mgrt_plan *p, int l, R *u, const R *u_in, const R *f, R o
     int nx[16], ny[16], nz[16];
     for (int m = l; m < n; ++m)
         nx[m - l] = p->lv[m].g.nx, ny[m - l] = p->lv[m].g.ny, nz[m - l] = p->lv[m].g.nz;
-    return bottom_cycle(n - l, nx, ny, nz, p->lv[l].g.face, p->desc.zfull, u, u_in, f, omega, a1, a2, v, p->stream);
+    return bottom_cycle(p->desc.dim, n - l, nx, ny, nz, p->lv[l].g.face, p->desc.zfull, u, u_in, f, omega, a1, a2, v, p->stream);
 }
 
 // The fused sweep kernels cover analytic-box levels; levels with a byte map smooth in place with
