@@ -177,8 +177,9 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
             return st;
         u_is_zero = false;
     }
-    // On bandwidth-bound levels the last pre-smoothing sweep carries the residual pass along.
-    const bool res_in_sweep = L.g.dim == 3 && n1 > 0 && v > 0 && recurses(L.g) && !latency_bound_level(L.g) && !p->fuse_rr;
+    // On bandwidth-bound levels the last pre-smoothing sweep carries the residual pass along
+    // (4-byte elements: with 8-byte ones the narrower strips make it slower than the two kernels).
+    const bool res_in_sweep = sizeof(R) == 4 && L.g.dim == 3 && n1 > 0 && v > 0 && recurses(L.g) && !latency_bound_level(L.g) && !p->fuse_rr;
     if (a1 > 0)
         if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a1, n1, res_in_sweep ? (R *)L.r : nullptr, u_is_zero))
             return st;

@@ -358,7 +358,7 @@ template <> struct Cfg<float> {
 };
 template <> struct Cfg<double> {
     static constexpr int SR1 = 4, NW1 = 4, PF1 = 4;
-    static constexpr int SR2 = 2, NW2 = 12, PF2 = 3;
+    static constexpr int SR2 = 4, NW2 = 8, PF2 = 2; // 238-246 registers: one block of 8 waves per CU
     static constexpr int NWS2 = 12, PFS2 = 3;
 };
 
@@ -403,6 +403,17 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
             case 10: return launch<R, 2, 6, 4, 3>(g, out, in, f, omega, zcount, hs);
             case 11: return launch<R, 2, 4, 3, 3>(g, out, in, f, omega, zcount, hs);
             case 12: return launch<R, 2, 8, 2, 2>(g, out, in, f, omega, zcount, hs);
+            }
+        }
+        if (sizeof(R) == 8 && iters == 2) {
+            switch (c) {
+            case 1: return launch<R, 2, 2, 8, 3>(g, out, in, f, omega, zcount, hs);
+            case 2: return launch<R, 2, 2, 16, 3>(g, out, in, f, omega, zcount, hs);
+            case 3: return launch<R, 2, 2, 12, 2>(g, out, in, f, omega, zcount, hs);
+            case 4: return launch<R, 2, 2, 12, 6>(g, out, in, f, omega, zcount, hs);
+            case 5: return launch<R, 2, 4, 4, 3>(g, out, in, f, omega, zcount, hs);
+            case 6: return launch<R, 2, 4, 8, 2>(g, out, in, f, omega, zcount, hs);
+            case 7: return launch<R, 2, 4, 6, 3>(g, out, in, f, omega, zcount, hs);
             }
         }
         if (sizeof(R) == 4 && iters == 1) {
