@@ -60,30 +60,50 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
 {
     extern __shared__ __align__(16) unsigned char smem[];
     R *const base = reinterpret_cast<R *>(smem);
-    // Level geometry and array placement are recomputed from the kernel arguments (scalar loads)
-    // wherever they are needed: arrays of pointers indexed by a run-time level would live in
-    // scratch memory.  Level m occupies 3 arrays of n_m elements (u, f, r), the last one 2.
+    // Level geometry and array placement sit in LDS: indexing the kernel argument arrays (or local
+    // arrays of pointers) with a run-time level makes the compiler move them to scratch memory,
+    // which costs a memory round trip per phase.  Level m occupies 3 arrays of n_m elements
+    // (u, f, r), the last one 2.
+    __shared__ int s_geo[kMaxLev][4]; // nx, ny, nz, offset of u
+    if (threadIdx.x == 0) {
+        int off = 0;
+#pragma unroll
+        for (int m = 0; m < kMaxLev; ++m) {
+            s_geo[m][0] = A.nx[m], s_geo[m][1] = A.ny[m], s_geo[m][2] = A.nz[m], s_geo[m][3] = off;
+            off += m < A.nlev ? 3 * A.nx[m] * A.ny[m] * A.nz[m] : 0;
+        }
+    }
+    __syncthreads();
     auto level = [&](int l) {
         Lvl L;
-        L.nx = A.nx[l], L.ny = A.ny[l], L.nz = A.nz[l];
+        L.nx = s_geo[l][0], L.ny = s_geo[l][1], L.nz = s_geo[l][2];
         L.p = L.nx, L.s = L.nx * L.ny, L.n = L.s * L.nz;
         L.zcount = DIM == 2 || A.zfull ? L.nz : L.nz / 2 + L.nz % 2; // multigridsolver3D.cpp:121
         return L;
     };
-    auto u_of = [&](int l) {
-        int off = 0;
-        for (int m = 0; m < l; ++m)
-            off += 3 * A.nx[m] * A.ny[m] * A.nz[m];
-        return base + off;
-    };
+    auto u_of = [&](int l) { return base + s_geo[l][3]; };
     const int tid = threadIdx.x;
     const int(&face)[6] = A.face;
 
     {
+        // loads in batches of 8 per thread: a plain loop would wait for each load in turn
         const int n0 = A.nx[0] * A.ny[0] * A.nz[0];
-        for (int i = tid; i < n0; i += kThreads) {
-            base[i] = u_in ? u_in[i] : (R)0;
-            base[n0 + i] = f_in[i];
+        for (int i0 = 0; i0 < n0; i0 += 8 * kThreads) {
+            R ru[8], rf[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + tid + k * kThreads;
+                ru[k] = i < n0 && u_in ? u_in[i] : (R)0;
+                rf[k] = i < n0 ? f_in[i] : (R)0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + tid + k * kThreads;
+                if (i < n0) {
+                    base[i] = ru[k];
+                    base[n0 + i] = rf[k];
+                }
+            }
         }
     }
     __syncthreads();
@@ -321,7 +341,7 @@ mgrt_status bottom(int dim, int nlev, const int *nx, const int *ny, const int *n
     MGRT_REQUIRE(v < 256, "bottom cycle: %d coarse solves per level", v);
     const size_t need = lds_need<R>(nlev, nx, ny, nz);
     MGRT_REQUIRE(need <= kLdsBudget, "bottom cycle: %zu bytes of LDS needed", need);
-    BottomArgs A;
+    BottomArgs A = {};
     A.dim = dim;
     A.nlev = nlev;
     for (int l = 0; l < nlev; ++l)

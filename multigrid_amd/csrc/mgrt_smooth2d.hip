@@ -37,12 +37,25 @@ __global__ __launch_bounds__(kThreads) void k_smooth2d_fused(mgrt_grid g, const 
     const int x0 = (tile % ntx) * kTX - H, y0 = (tile / ntx) * kTY - H;
     const long long p = g.pitch;
 
-    for (int i = threadIdx.x; i < W * HT; i += kThreads) {
+    // all loads of the tile are issued before the first one is consumed
+    constexpr int NL = (W * HT + kThreads - 1) / kThreads;
+    R ru[NL], rf[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int i = threadIdx.x + k * kThreads;
         const int lx = i % W, ly = i / W, x = x0 + lx, y = y0 + ly;
-        const bool live = x >= 0 && x < g.nx && y >= 0 && y < g.ny;
+        const bool live = i < W * HT && x >= 0 && x < g.nx && y >= 0 && y < g.ny;
         const long long b = x + p * y;
-        su[ly][lx] = live && in ? in[b] : (R)0; // in == nullptr stands for a field of zeros
-        sf[ly][lx] = live ? f[b] : (R)0;
+        ru[k] = live && in ? in[b] : (R)0; // in == nullptr stands for a field of zeros
+        rf[k] = live ? f[b] : (R)0;
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int i = threadIdx.x + k * kThreads;
+        if (i < W * HT) {
+            su[i / W][i % W] = ru[k];
+            sf[i / W][i % W] = rf[k];
+        }
     }
     __syncthreads();
 
