@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmgrt.so")
+LIB_PATH = os.environ.get("MGRT_LIB") or os.path.join(_HERE, "libmgrt.so")  # MGRT_LIB: development, A/B builds
 
 INNER, OUTER, DIRICHLET, NEUMANN = 0, 1, 2, 3
 ALL_DIRICHLET = (DIRICHLET,) * 6

@@ -353,7 +353,7 @@ mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega,
 template <class R> struct Cfg;
 template <> struct Cfg<float> {
     static constexpr int SR1 = 4, NW1 = 8, PF1 = 4; // one iteration per sweep: 4 planes prefetched
-    static constexpr int SR2 = 4, NW2 = 8, PF2 = 3; // two iterations per sweep: 3 planes prefetched
+    static constexpr int SR2 = 4, NW2 = 8, PF2 = 2; // two iterations per sweep: 2 planes prefetched
     static constexpr int NWS2 = 8, PFS2 = 3;        // waves per block and prefetch depth of the small-level shape
 };
 template <> struct Cfg<double> {
@@ -403,6 +403,10 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
             case 10: return launch<R, 2, 6, 4, 3>(g, out, in, f, omega, zcount, hs);
             case 11: return launch<R, 2, 4, 3, 3>(g, out, in, f, omega, zcount, hs);
             case 12: return launch<R, 2, 8, 2, 2>(g, out, in, f, omega, zcount, hs);
+            case 13: return launch<R, 2, 4, 5, 3>(g, out, in, f, omega, zcount, hs);
+            case 14: return launch<R, 2, 4, 5, 2>(g, out, in, f, omega, zcount, hs);
+            case 15: return launch<R, 2, 4, 6, 3>(g, out, in, f, omega, zcount, hs);
+            case 16: return launch<R, 2, 4, 7, 3>(g, out, in, f, omega, zcount, hs);
             }
         }
         if (sizeof(R) == 8 && iters == 2) {
@@ -434,13 +438,31 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
 #endif
     // strips of two rows halve the work a wave does per step (measured 25-30 % faster from 257^2 down)
     const bool small = latency_bound_level(*g);
+#ifdef MGRT_TUNE
+    if (const char *e = getenv("MGRT_SWEEP_CFG")) {
+        if (res && sizeof(R) == 4 && iters == 2) {
+            switch (atoi(e)) {
+            case 1: return launch<R, 2, 4, 8, 2, true>(g, out, in, f, omega, zcount, hs, res);
+            case 2: return launch<R, 2, 4, 6, 2, true>(g, out, in, f, omega, zcount, hs, res);
+            case 3: return launch<R, 2, 4, 6, 4, true>(g, out, in, f, omega, zcount, hs, res);
+            case 4: return launch<R, 2, 4, 5, 2, true>(g, out, in, f, omega, zcount, hs, res);
+            case 5: return launch<R, 2, 4, 7, 2, true>(g, out, in, f, omega, zcount, hs, res);
+            case 6: return launch<R, 2, 4, 10, 2, true>(g, out, in, f, omega, zcount, hs, res);
+            case 7: return launch<R, 2, 2, 8, 2, true>(g, out, in, f, omega, zcount, hs, res);
+            case 8: return launch<R, 2, 4, 4, 2, true>(g, out, in, f, omega, zcount, hs, res);
+            case 9: return launch<R, 2, 6, 6, 2, true>(g, out, in, f, omega, zcount, hs, res);
+            }
+        }
+    }
+#endif
     if (res) {
-        constexpr bool wide = sizeof(R) == 4; // strips of four rows only with 4-byte elements (registers)
+        // Strips of four rows only with 4-byte elements (registers).  Shapes chosen by timing whole
+        // cycles: kernel-only timings on warm caches favour other shapes that lose in the cycle.
         if (iters == 1)
-            return small || !wide ? launch<R, 1, 2, 8, 3, true>(g, out, in, f, omega, zcount, hs, res)
-                                  : launch<R, 1, wide ? 4 : 2, 8, 3, true>(g, out, in, f, omega, zcount, hs, res);
-        return small || !wide ? launch<R, 2, 2, 8, 4, true>(g, out, in, f, omega, zcount, hs, res)
-                              : launch<R, 2, wide ? 4 : 2, 8, 4, true>(g, out, in, f, omega, zcount, hs, res);
+            return small || sizeof(R) == 8 ? launch<R, 1, 2, 8, 3, true>(g, out, in, f, omega, zcount, hs, res)
+                                           : launch<R, 1, sizeof(R) == 4 ? 4 : 2, 8, 3, true>(g, out, in, f, omega, zcount, hs, res);
+        return small || sizeof(R) == 8 ? launch<R, 2, 2, 8, 4, true>(g, out, in, f, omega, zcount, hs, res)
+                                       : launch<R, 2, sizeof(R) == 4 ? 4 : 2, 8, 4, true>(g, out, in, f, omega, zcount, hs, res);
     }
     if (iters == 1)
         return small ? launch<R, 1, 2, 8, 4>(g, out, in, f, omega, zcount, hs)
