@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Per-level, per-kernel achieved bandwidth of the 3D V-cycle from a rocprofv3 --kernel-trace run of
+bench.py.  The level of a dispatch follows from its place in the cycle: the level goes up by one
+after every restriction, the one-launch bottom stands for all remaining levels, and every
+interpolation belongs to the level above the one just left.
+
+usage: level_report.py <rocprof output dir> [n=513] [elem_bytes=4]"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+PEAK = 8000.0  # GB/s
+
+
+def main():
+    root = sys.argv[1]
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 513
+    w = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    sizes = [n]
+    while sizes[-1] > 3:
+        sizes.append((sizes[-1] + 1) // 2)
+    pts = [s ** 3 for s in sizes]
+    rows = []
+    for path in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    # the cycles end with the sweep that follows the last correction; what bench.py launches after
+    # that (its timing loop over the dominant kernel) is not part of a cycle
+    last = max((i for i, r in enumerate(rows) if "k_interp3d_v" in r[2]), default=None)
+    if last is not None:
+        end = next((i for i in range(last + 1, len(rows)) if "k_smooth3d_fused" in rows[i][2]), len(rows) - 1)
+        rows = rows[:end + 1]
+    agg = defaultdict(list)
+    level = 0
+    for t0, t1, name in rows:
+        m = re.search(r"(k_\w+)<([^>]*)>", name)
+        if not m:
+            continue
+        k, targs = m.group(1), [a.strip() for a in m.group(2).split(",")]
+        dur = (t1 - t0) * 1e-3
+        if k == "k_smooth3d_fused":
+            res = targs[-1] == "true"
+            fam = "sweep x%s%s" % (targs[1], " + residual" if res else "")
+            byts = (4 if res else 3) * pts[level] * w
+        elif k == "k_residual3d_v":
+            if targs[-1] == "true":     # with the norm: the history between cycles, level 0
+                agg[(0, "residual + norm (history)", 3 * pts[0] * w)].append(dur)
+                level = 0
+                continue
+            fam, byts = "residual", 3 * pts[level] * w
+        elif k == "k_restrict":
+            fam, byts = "restrict", (pts[level] + pts[level + 1]) * w
+        elif k == "k_interp3d_v":
+            level -= 1
+            fam, byts = "correct", (2 * pts[level] + pts[level + 1]) * w
+        elif k == "k_bottom_cycle":
+            fam, byts = "bottom cycle (levels %d..%d)" % (level, len(sizes) - 1), 0
+        else:
+            continue
+        agg[(level, fam, byts)].append(dur)
+        if k == "k_restrict":
+            level += 1
+    print("3D %d^3, %d-byte elements; achieved = algorithmic bytes / mean kernel time; peak %.0f GB/s" % (n, w, PEAK))
+    print("%-5s %-8s %-34s %6s %10s %10s %7s" % ("level", "extent", "kernel", "calls", "mean us", "GB/s", "% peak"))
+    for (lv, fam, byts), v in sorted(agg.items()):
+        mean = sum(v) / len(v)
+        gbs = byts / mean / 1e3 if byts else 0.0
+        print("%-5d %-8s %-34s %6d %10.1f %10.0f %6.1f%%" % (lv, "%d^3" % sizes[lv], fam, len(v), mean, gbs, 100 * gbs / PEAK))
+    per_level = defaultdict(float)
+    cycles = max(1, len(agg.get((0, "restrict", (pts[0] + pts[1]) * w), [])))
+    for (lv, fam, byts), v in agg.items():
+        if "history" not in fam:
+            per_level[lv] += sum(v) / cycles
+    print("per cycle: " + ", ".join("L%d %.0f us" % (l, t) for l, t in sorted(per_level.items())) +
+          "; total %.0f us" % sum(per_level.values()))
+
+
+if __name__ == "__main__":
+    main()
