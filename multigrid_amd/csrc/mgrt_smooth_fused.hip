@@ -158,6 +158,18 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
     // class of a point is a per-lane constant.
     auto group = [&](auto fast_tag, const int i0) {
         constexpr bool FAST = decltype(fast_tag)::value;
+        // Plane addresses of a fast group advance by one slab per step: keep running pointers
+        // (two scalar adds each) instead of a 64-bit multiply per array and step.
+        // The descriptors themselves are the running state: base address in words 0 and 1.
+        desc_t d_in = plane_desc(inb + slab * (i0 + PD), in_bytes), d_f = plane_desc(f + slab * (i0 + PD), plane_bytes);
+        desc_t d_out = plane_desc(out + slab * (i0 - NP), plane_bytes);
+        desc_t d_res = plane_desc(RES ? res + slab * (i0 - DR) : out, plane_bytes);
+        const unsigned long long slab_bytes = (unsigned long long)slab * sizeof(R);
+        auto advance = [&](desc_t &d) {
+            const unsigned long long a = (((unsigned long long)(unsigned)d.y << 32) | (unsigned)d.x) + slab_bytes;
+            d.x = (int)(unsigned)a;
+            d.y = (int)(unsigned)(a >> 32); // addresses stay below 2^48: the upper half of word 1 stays 0
+        };
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int i = i0 + u; // plane entering the ring; i0 is a multiple of UN
@@ -188,8 +200,9 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                 }
                 { // plane i + PD -> prefetch slot ps
                     const int zn = i + PD;
-                    const long long zo = slab * (FAST || zn < zlast ? zn : zlast);
-                    const desc_t ru = plane_desc(inb + zo, in_bytes), rf = plane_desc(f + zo, plane_bytes);
+                    const long long zo = slab * (zn < zlast ? zn : zlast);
+                    const desc_t ru = FAST ? d_in : plane_desc(inb + zo, in_bytes);
+                    const desc_t rf = FAST ? d_f : plane_desc(f + zo, plane_bytes);
 #pragma unroll
                     for (int r = 0; r < SR; ++r) {
                         buf_load_hidden(pu[ps][r], ru, off[r]);
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                 // ---- plane i - NP is final: store the tile's interior ----------------------------
                 const int zf = i - NP;
                 if (FAST || (zf >= 0 && zf <= zlast)) {
-                    const desc_t ro = plane_desc(out + slab * zf, plane_bytes);
+                    const desc_t ro = FAST ? d_out : plane_desc(out + slab * zf, plane_bytes);
 #pragma unroll
                     for (int r = 0; r < SR; ++r)
                         buf_store_hidden(((r & 1) ^ s0) ? C[1][PH(NP)][r / 2] : C[0][PH(NP)][r / 2], ro, soff[r]);
@@ -289,13 +302,18 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                                 rv[c][j] = is_in ? vi : (is_dir ? vd : (R)0);
                             }
                         }
-                        const desc_t rr = plane_desc(res + slab * z, plane_bytes);
+                        const desc_t rr = FAST ? d_res : plane_desc(res + slab * z, plane_bytes);
 #pragma unroll
                         for (int r = 0; r < SR; ++r)
                             buf_store_hidden(((r & 1) ^ s0) ? rv[1][r / 2] : rv[0][r / 2], rr, soff[r]);
                     }
                 }
 #undef PH
+                if (FAST) {
+                    advance(d_in), advance(d_f), advance(d_out);
+                    if (RES)
+                        advance(d_res);
+                }
             }
         }
     };
