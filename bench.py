@@ -9,7 +9,7 @@ value = finest-grid points x cycles / second over all GPUs.
 
 For N > 1 the driver launches one process per GPU with torch.distributed.run; the 513^3 grid is cut
 into N slabs along y (multigrid_amd/dist.py): halo exchange over RCCL before each fused sweep, the
-levels of at most 65^3 points solved whole on every rank.  Total work is fixed: strong scaling.
+levels of at most 129^3 points solved whole on every rank.  Total work is fixed: strong scaling.
 """
 import argparse
 import json
@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a one-GPU box: every rank on cuda:0, gloo with host staging; checks that the "
                          "path runs, the number is not a measurement")
-    ap.add_argument("--crossover", type=int, default=65 ** 3,
+    ap.add_argument("--crossover", type=int, default=129 ** 3,
                     help="N > 1: levels with at most this many points are solved whole on every rank")
     args = ap.parse_args()
 
