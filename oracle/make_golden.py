@@ -33,7 +33,7 @@ for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
     CASES.append(("3d_17_%s_fmg_default" % tag, 0, (17, 17, 17), dt, 0, 1.0, 3, 3, 2, 3, "fmg"))
     CASES.append(("3d_17_%s_fmg_zfull" % tag, 0, (17, 17, 17), dt, 1, 1.0, 3, 3, 2, 3, "fmg"))
     CASES.append(("2d_33_%s_fmg_default" % tag, 1, (33, 33), dt, 0, 1.0, 3, 3, 2, 3, "fmg"))
-# BASELINE config 1: 2D 257^2 Dirichlet V(2,2), float: history plus field
+# the CPU-runnable case of the benchmark set: 2D 257^2 Dirichlet V(2,2), float: history plus field
 CASES.append(("2d_257_f32_v22", 1, (257, 257), np.float32, 0, 1.0, 2, 2, 1, 6, "mg"))
 
 

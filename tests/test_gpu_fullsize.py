@@ -49,7 +49,7 @@ def run(shape, dtype, dev, cycles, faces=None, **kw):
 
 
 def test_513_cubed_f32_fused_equals_unfused(dev):
-    """BASELINE config 4 on one GPU: 3D 513^3 Dirichlet, V(2,2)."""
+    """The headline case on one GPU: 3D 513^3 Dirichlet, V(2,2)."""
     import torch
     shape = (513, 513, 513)
     u1, f, h1 = run(shape, torch.float32, dev, 2, use_graph=True)
@@ -61,7 +61,7 @@ def test_513_cubed_f32_fused_equals_unfused(dev):
 
 
 def test_257_cubed_neumann_faces_are_frozen(dev):
-    """BASELINE config 3: 3D 257^3 with Neumann faces, which the reference never updates, and the
+    """3D 257^3 with Neumann faces, which the reference never updates, and the
     Dirichlet variant of the same grid."""
     import torch
     from multigrid_amd import _lib as L
@@ -79,7 +79,7 @@ def test_257_cubed_neumann_faces_are_frozen(dev):
 
 
 def test_1025_cubed_f64_one_cycle(dev):
-    """BASELINE config 5 on one GPU: 3D 1025^3 in double."""
+    """The largest case, on one GPU: 3D 1025^3 in double."""
     import torch
     shape = (1025, 1025, 1025)
     u1, f, h1 = run(shape, torch.float64, dev, 1, use_graph=True)
@@ -91,7 +91,7 @@ def test_1025_cubed_f64_one_cycle(dev):
 
 
 def test_4097_squared_f32_mixed_faces(dev):
-    """BASELINE config 2: 2D 4097^2, Dirichlet on the x faces, Neumann (frozen) on the y faces."""
+    """2D 4097^2, Dirichlet on the x faces, Neumann (frozen) on the y faces."""
     import torch
     from multigrid_amd import _lib as L
     shape = (4097, 4097)

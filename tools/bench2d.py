@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""development: time 2D V(2,2) cycles (BASELINE config 2: 4097^2, x faces Dirichlet, y faces Neumann)"""
+"""development: time 2D V(2,2) cycles (4097^2, x faces Dirichlet, y faces Neumann)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

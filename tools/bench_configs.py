@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Cycle time of every BASELINE configuration that fits one GPU (bench.py reports only the headline
+"""Cycle time of every benchmark configuration that fits one GPU (bench.py reports only the headline
 one): V(2,2), omega 1, fields resident in HBM, graph replay, 3D smoother over all planes."""
 import json
 import os
