@@ -603,85 +603,13 @@ __global__ __launch_bounds__(256) void k_interp(mgrt_grid fg, mgrt_grid cg, R *o
     out[d] = MODE == 0 ? u[d] + val * 4 : val;
 }
 
-// 3D interpolation as a z-march: one thread owns fine column x of the fine row pair (2j, 2j+1) and
-// walks a chunk of coarse planes, carrying the four coarse values of plane k+1 over as plane k of
-// the next step.  Per four fine points that is 4 coarse loads instead of 32, and the fine field is
-// read and written in full coalesced rows.  Same expressions, same operand order as k_interp.
-template <class R, bool MAP, int MODE, int ZC>
-__global__ __launch_bounds__(256) void k_interp3d_march(mgrt_grid fg, mgrt_grid cg, R *out, const R *u,
-                                                        const R *__restrict__ e, int ylo, int yhi, int ntx, int nty)
-{
-    const int ntiles = ntx * nty;
-    const int t = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int zc = t / ntiles, tile = t % ntiles;
-    const int x = (tile % ntx) * 64 + (threadIdx.x & 63);
-    // global coarse row handled by this thread; its fine rows are 2*cjg and 2*cjg+1
-    const int cjg = (ylo + fg.y0) / 2 + (tile / ntx) * 4 + (threadIdx.x >> 6);
-    if (x >= fg.nx)
-        return;
-    const int cj = cjg - cg.y0;
-    const int ci = x / 2;
-    const int ci1 = ci + 1 < cg.nx ? ci + 1 : ci;
-    const int cjc = cj < cg.ny ? cj : cg.ny - 1; // rows past the range are masked below
-    const int cj1 = cjc + 1 < cg.ny ? cjc + 1 : cjc;
-    const long long cp = cg.pitch, cs = cg.slab;
-    const long long o00 = ci + cp * cjc, o10 = ci1 + cp * cjc, o01 = ci + cp * cj1, o11 = ci1 + cp * cj1;
-    const R wu = 0.5 * (x % 2);
-    int yl[2];
-    bool rowok[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        yl[b] = 2 * cjg + b - fg.y0;
-        rowok[b] = yl[b] >= ylo && yl[b] < yhi;
-    }
-    const int kb = zc * ZC;
-    const int ke = kb + ZC < cg.nz ? kb + ZC : cg.nz;
-    R e0[4], e1[4];
-    {
-        const R *pl = e + cs * kb;
-        e1[0] = pl[o00], e1[1] = pl[o10], e1[2] = pl[o01], e1[3] = pl[o11];
-    }
-    for (int ck = kb; ck < ke; ++ck) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) e0[i] = e1[i];
-        {
-            const R *pl = e + cs * (ck + 1 < cg.nz ? ck + 1 : ck);
-            e1[0] = pl[o00], e1[1] = pl[o10], e1[2] = pl[o01], e1[3] = pl[o11];
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int z = 2 * ck + c;
-            if (z >= fg.nz)
-                break;
-            const R wv = 0.5 * c;
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                if (!rowok[b])
-                    continue;
-                const R ww = 0.5 * b;
-                const long long d = x + (long long)fg.pitch * yl[b] + fg.slab * z;
-                R val;
-                if (is_border(cell_class<3, MAP>(fg, x, yl[b], z))) {
-                    val = e0[0];
-                } else {
-                    const R n10 = (1.0 - wu) * (1.0 - ww) * (1.0 - wv), n11 = (1.0 - ww) * wu * (1.0 - wv),
-                            n12 = (1.0 - wu) * ww * (1.0 - wv), n13 = ww * wu * (1.0 - wv);
-                    const R n20 = (1.0 - wu) * (1.0 - ww) * wv, n21 = (1.0 - ww) * wu * wv,
-                            n22 = (1.0 - wu) * ww * wv, n23 = ww * wu * wv;
-                    val = dot4<R>(e0[0], e0[1], e0[2], e0[3], n10, n11, n12, n13) +
-                          dot4<R>(e1[0], e1[1], e1[2], e1[3], n20, n21, n22, n23);
-                }
-                out[d] = MODE == 0 ? u[d] + val * 4 : val;
-            }
-        }
-    }
-}
-
-// The same march with 16 bytes per lane on the fine side: a thread owns VX consecutive fine x
-// (4 floats / 2 doubles, starting at an even x) of the fine row pair (2j, 2j+1) and keeps the
-// VX/2+1 coarse values per coarse row and plane that they interpolate from.  Per 4*VX fine points
-// and coarse plane: 2*(VX/2+1) coarse loads, 4 wide loads of u, 4 wide stores.  `zchunk` coarse
-// planes per thread.  Same expressions, same operand order as k_interp.
+// 3D interpolation as a z-march with 16 bytes per lane on the fine side: a thread owns VX
+// consecutive fine x (4 floats / 2 doubles, starting at an even x) of the fine row pair (2j, 2j+1),
+// walks a chunk of coarse planes and carries the coarse values of plane k+1 over as plane k of the
+// next step; it keeps the VX/2+1 coarse values per coarse row and plane that its points
+// interpolate from.  Per 4*VX fine points and coarse plane: 2*(VX/2+1) coarse loads, 4 wide loads
+// of u, 4 wide stores.  `zchunk` coarse planes per thread.  Same expressions, same operand order as
+// k_interp.
 template <class R, bool MAP, int MODE>
 __global__ __launch_bounds__(256) void k_interp3d_v(mgrt_grid fg, mgrt_grid cg, R *out, const R *u,
                                                     const R *__restrict__ e, int ylo, int yhi, int ncrows,
