@@ -100,3 +100,34 @@ def test_4097_squared_f32_mixed_faces(dev):
     assert torch.equal(u[:, 0], f[:, 0]) and torch.equal(u[:, -1], f[:, -1])   # x faces: Dirichlet, u = f
     assert not u[0, 1:-1].any() and not u[-1, 1:-1].any()                      # y faces: never written
     assert h[-1] < h[0] and np.isfinite(h).all()
+
+
+@pytest.mark.parametrize("case", [
+    ((65, 513, 257), "f32", 0.9, 3, 1, 2, (2, 2, 2, 2, 2, 2)),
+    ((129, 129, 1025), "f32", 1.0, 1, 2, 1, (2, 3, 3, 2, 2, 3)),
+    ((257, 65, 513), "f64", 0.8, 2, 2, 1, (3, 2, 2, 1, 2, 2)),
+    ((33, 1025, 129), "f64", 1.0, 2, 3, 2, (2, 2, 2, 2, 2, 2)),
+], ids=lambda c: "x".join(map(str, c[0][::-1])) + "-" + c[1])
+def test_plan_paths_agree_on_anisotropic_grids(dev, case):
+    """Grids with unequal extents (levels stop when the shortest extent reaches 3), odd smoothing
+    counts, W-cycles, mixed face classes: fused and unfused plans, bit for bit, on random data."""
+    import torch
+    from multigrid_amd import _lib as L
+    shape, dt, omega, a1, a2, v, faces = case
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    torch.manual_seed(7)
+    f = torch.randn(shape, device=dev, dtype=tdt)
+    u0 = torch.randn(shape, device=dev, dtype=tdt)
+    outs = []
+    for kw in (dict(use_graph=True), dict(no_fuse=True)):
+        u = u0.clone()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            plan = L.Plan(shape, tdt, faces=faces, zfull=True, **kw)
+            plan.vcycle(u, f, omega, a1, a2, v, 2)
+            plan.close()
+        torch.cuda.synchronize()
+        outs.append(u)
+    assert torch.equal(outs[0].view(torch.uint8), outs[1].view(torch.uint8))
+    assert torch.isfinite(outs[0]).all()
