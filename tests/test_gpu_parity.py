@@ -243,7 +243,7 @@ def test_cycle_on_wide_planes_matches_oracle(dev, mgo, v):
 @pytest.mark.parametrize("shape", [(5, 5), (9, 17), (33, 65), (64, 70), (130, 67), (257, 129)],
                          ids=lambda s: "x".join(map(str, s[::-1])))
 def test_fused_sweep_2d_matches_oracle(dev, mgo, dt, shape):
-    """2D: out = S^iters(in) from LDS tiles against 2*iters single-colour passes of the oracle,
+    """2D: out = S^iters(in) from register-resident tiles against 2*iters single-colour passes of the oracle,
     whole grids and a y-slab, and the zero-input form."""
     import torch
     from multigrid_amd import _lib as L
