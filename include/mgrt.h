@@ -114,10 +114,18 @@ mgrt_status mgrt_box_cells_host(int dim, int nx, int ny, int nz, const int face[
                                      int iters, int zcount, mgrt_stream s);                        \
     /* The same sweep, which also leaves r = residual of `out` (as mgrt_residual with               \
        zero_unwritten) behind: smoother_iterate followed by compute_residuals                      \
-       (multigridsolver3D.cpp:50,61) in one pass over the fields.  Same restrictions. */           \
+       (multigridsolver3D.cpp:50,61, multigridsolver2D.cpp:51,62) in one pass over the fields.     \
+       Same restrictions. */                                                                       \
     mgrt_status mgrt_smooth_sweep_residual##S(const mgrt_grid *g, R *out, R *r, const R *in,       \
                                               const R *f, R omega, int iters, int zcount,          \
                                               mgrt_stream s);                                      \
+    /* out = S^iters(u + 4*P(e)): the results of mgrt_correct followed by mgrt_smooth_sweep, the   \
+       corrected field never written.  Replaces correct_residual followed by the post-smoothing    \
+       smoother_iterate (multigridsolver2D.cpp:77,92).  2D analytic-box grids only                 \
+       (MGRT_E_UNSUPPORTED otherwise: call the two kernels).  out must not alias an input. */      \
+    mgrt_status mgrt_correct_smooth_sweep##S(const mgrt_grid *fine, const mgrt_grid *coarse,       \
+                                             R *out, const R *u, const R *e, const R *f, R omega,  \
+                                             int iters, int zcount, mgrt_stream s);                \
     /* r = f - A u on inner cells, f - u on Dirichlet cells; outer and Neumann cells of r are     \
        left untouched, or set to 0 when zero_unwritten != 0.  Replaces residual_kernel            \
        (mg_1.cl:111-133, mg_0.cl:105-126).  norm2 (device, may be NULL) receives sum(r*r) over    \

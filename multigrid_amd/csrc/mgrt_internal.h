@@ -66,11 +66,13 @@ mgrt_status bottom_cycle(int dim, int nlev, const int *nx, const int *ny, const 
                          double *u, const double *u_in, const double *f, double omega, int a1, int a2, int v,
                          hipStream_t hs);
 
-// out = S^iters(in) on a 2D analytic-box grid, iters 1 or 2 (mgrt_smooth2d.hip); in may be null
-mgrt_status smooth_sweep_2d(const mgrt_grid *g, float *out, const float *in, const float *f, float omega, int iters,
-                            hipStream_t hs);
-mgrt_status smooth_sweep_2d(const mgrt_grid *g, double *out, const double *in, const double *f, double omega, int iters,
-                            hipStream_t hs);
+// out = S^iters(in) on a 2D analytic-box grid, iters 1 or 2 (mgrt_smooth2d.hip); in may be null.
+// res (optional) receives the residual of out; e with its coarse grid cg (optional) makes the input
+// in + 4*P(e).
+mgrt_status smooth_sweep_2d(const mgrt_grid *g, const mgrt_grid *cg, float *out, float *res, const float *in,
+                            const float *e, const float *f, float omega, int iters, hipStream_t hs);
+mgrt_status smooth_sweep_2d(const mgrt_grid *g, const mgrt_grid *cg, double *out, double *res, const double *in,
+                            const double *e, const double *f, double omega, int iters, hipStream_t hs);
 
 } // namespace mgrt
 

@@ -71,6 +71,7 @@ template <> struct K<float> {
     static constexpr auto smooth = mgrt_smooth_f32;
     static constexpr auto sweep = mgrt_smooth_sweep_f32;
     static constexpr auto sweep_res = mgrt_smooth_sweep_residual_f32;
+    static constexpr auto correct_sweep = mgrt_correct_smooth_sweep_f32;
     static constexpr auto residual = mgrt_residual_f32;
     static constexpr auto restrict_ = mgrt_restrict_f32;
     static constexpr auto resrestrict = mgrt_residual_restrict_f32;
@@ -81,6 +82,7 @@ template <> struct K<double> {
     static constexpr auto smooth = mgrt_smooth_f64;
     static constexpr auto sweep = mgrt_smooth_sweep_f64;
     static constexpr auto sweep_res = mgrt_smooth_sweep_residual_f64;
+    static constexpr auto correct_sweep = mgrt_correct_smooth_sweep_f64;
     static constexpr auto residual = mgrt_residual_f64;
     static constexpr auto restrict_ = mgrt_restrict_f64;
     static constexpr auto resrestrict = mgrt_residual_restrict_f64;
@@ -125,10 +127,11 @@ bool sweepable(const mgrt_plan *p, const mgrt_grid &g) { return !p->desc.no_fuse
 
 // `a` smoothing iterations on *cur, as `nsweeps` out-of-place fused sweeps that ping-pong between
 // *cur and *alt (nsweeps between ceil(a/2) and a), or in place when nsweeps == 0.  With `res`, the
-// last sweep also leaves the residual of the result there (nsweeps > 0 only).
+// last sweep also leaves the residual of the result there; with `e` (on the coarse grid `cg`), the
+// first sweep starts from *cur + 4*P(e), the coarse-grid correction (both: nsweeps > 0 only).
 template <class R>
 mgrt_status smooth_steps(mgrt_plan *p, mgrt_plan::Level &L, R *&cur, R *&alt, const R *f, R omega, int a, int nsweeps,
-                         R *res = nullptr, bool cur_is_zero = false)
+                         R *res = nullptr, bool cur_is_zero = false, const mgrt_grid *cg = nullptr, const R *e = nullptr)
 {
     mgrt_stream s = (mgrt_stream)p->stream;
     const int zc = zcount_of(p, L.g);
@@ -139,8 +142,9 @@ mgrt_status smooth_steps(mgrt_plan *p, mgrt_plan::Level &L, R *&cur, R *&alt, co
         const int n = i < a - nsweeps ? 2 : 1;
         // a field known to be all zeros is not read (and was not cleared): the kernel takes NULL
         const R *in = cur_is_zero && i == 0 ? nullptr : cur;
-        if (mgrt_status st = res && i + 1 == nsweeps ? K<R>::sweep_res(&L.g, alt, res, in, f, omega, n, zc, s)
-                                                     : K<R>::sweep(&L.g, alt, in, f, omega, n, zc, s))
+        if (mgrt_status st = e && i == 0              ? K<R>::correct_sweep(&L.g, cg, alt, cur, e, f, omega, n, zc, s)
+                             : res && i + 1 == nsweeps ? K<R>::sweep_res(&L.g, alt, res, in, f, omega, n, zc, s)
+                                                       : K<R>::sweep(&L.g, alt, in, f, omega, n, zc, s))
             return st;
         R *t = cur;
         cur = alt;
@@ -179,7 +183,11 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
     }
     // On bandwidth-bound levels the last pre-smoothing sweep carries the residual pass along
     // (4-byte elements: with 8-byte ones the narrower strips make it slower than the two kernels).
-    const bool res_in_sweep = sizeof(R) == 4 && L.g.dim == 3 && n1 > 0 && v > 0 && recurses(L.g) && !latency_bound_level(L.g) && !p->fuse_rr;
+    // In 2D every fused level does, and the last correction goes into the first post-smoothing sweep.
+    const bool res_in_sweep =
+        n1 > 0 && v > 0 && recurses(L.g) &&
+        (L.g.dim == 2 || (sizeof(R) == 4 && L.g.dim == 3 && !latency_bound_level(L.g) && !p->fuse_rr));
+    const bool correct_in_sweep = L.g.dim == 2 && n2 > 0 && a2 > 0 && v > 0 && recurses(L.g);
     if (a1 > 0)
         if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a1, n1, res_in_sweep ? (R *)L.r : nullptr, u_is_zero))
             return st;
@@ -201,13 +209,17 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
             if (mgrt_status st = iterate<R>(p, l + 1, (R *)C.e, (const R *)C.rhs, omega, a1, a2, v, true)) // zero_mem(i), :59
                 return st;
             // in place: same values as the out-of-place kernel followed by the handle swap (:70-72)
-            if (mgrt_status st = K<R>::correct(&L.g, &C.g, cur, cur, (const R *)C.e, 0, L.g.ny, s))
-                return st;
+            if (!(correct_in_sweep && k + 1 == v))
+                if (mgrt_status st = K<R>::correct(&L.g, &C.g, cur, cur, (const R *)C.e, 0, L.g.ny, s))
+                    return st;
         }
     }
-    if (a2 > 0)
-        if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a2, n2))
+    if (a2 > 0) {
+        const mgrt_grid *cg = correct_in_sweep ? &p->lv[l + 1].g : nullptr;
+        if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a2, n2, nullptr, false, cg,
+                                             correct_in_sweep ? (const R *)p->lv[l + 1].e : nullptr))
             return st;
+    }
     if (cur != u) // odd number of sweeps (only when a1 + a2 == 1): bring the result home
         MGRT_HIP(hipMemcpyAsync(u, cur, L.n * sizeof(R), hipMemcpyDeviceToDevice, p->stream));
     return MGRT_OK;

@@ -24,10 +24,10 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 
-// waves per SIMD the register file admits with 2*RT values per lane and some room to work in
-template <class R, int RT> constexpr int cols_waves()
+// waves per SIMD the register file admits with `values` field values per lane and some room to work in
+template <class R, int values> constexpr int cols_waves()
 {
-    constexpr int need = 2 * RT * (int)(sizeof(R) / 4) + 40, w = 512 / need;
+    constexpr int need = values * (int)(sizeof(R) / 4) + 40, w = 512 / need;
     return w < 1 ? 1 : w > 8 ? 8 : w;
 }
 
@@ -40,11 +40,18 @@ __device__ __forceinline__ int per_pass(int v)
     return v;
 }
 
-template <class R, int ITERS, int RT, bool OMEGA1, bool ZERO_IN>
-__global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, RT>())) void k_smooth2d_cols(
-    mgrt_grid g, const R *__restrict__ in, R *__restrict__ out, const R *__restrict__ f, R omega, int ntx, int ntiles)
+// Where the tile's input comes from: a field, zeros, or a field plus the interpolated coarse-grid
+// correction (the input of the post-smoother).
+enum Input { FIELD, ZEROS, CORRECTED };
+
+// RES: also r = residual of `out`, which takes one more halo ring (the residual of a point reads
+// the final values of its four neighbours).
+template <class R, int ITERS, int RT, bool OMEGA1, Input IN, bool RES>
+__global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN == CORRECTED ? RT + 4 : 0)>())) void k_smooth2d_cols(
+    mgrt_grid g, mgrt_grid cg, const R *__restrict__ in, R *__restrict__ out, const R *__restrict__ f,
+    const R *__restrict__ e, R *__restrict__ res, R omega, int ntx, int ntiles)
 {
-    constexpr int H = 2 * ITERS, OX = 64 - 2 * H, OY = RT - 2 * H;
+    constexpr int H = 2 * ITERS + (RES ? 1 : 0), OX = 64 - 2 * H, OY = RT - 2 * H;
     static_assert(OY > 0, "tile too short for its halo");
     const int lane = threadIdx.x & 63;
     // the wave index through readfirstlane: everything derived from the tile stays in scalar registers
@@ -59,13 +66,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, RT>())) void k_
 
     // Cells outside the grid are never relaxed and never read by a cell that is, so their loads only
     // have to be safe: the coordinates are clamped into the grid instead of predicated.
-    const long long at = min(max(x, 0), nx - 1) + pitch * (long long)(y0 + first);
+    const int xc = min(max(x, 0), nx - 1);
+    const long long at = xc + pitch * (long long)(y0 + first);
     const R *pf = f + at;
-    const R *pu = (ZERO_IN ? f : in) + at;
+    const R *pu = (IN == ZEROS ? f : in) + at;
     R u[RT], b[RT];
 #pragma unroll
     for (int j = 0; j < RT; ++j) {
-        u[j] = ZERO_IN ? (R)0 : *pu;
+        u[j] = IN == ZEROS ? (R)0 : *pu;
         b[j] = *pf;
         const long long step = j >= first && j < last ? pitch : 0; // next row, clamped
         pf += step;
@@ -76,11 +84,50 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, RT>())) void k_
     const bool x_inner = x > 0 && x < nx - 1;
     const bool x_dirichlet = (x == 0 && g.face[0] == MGRT_CELL_DIRICHLET) || (x == nx - 1 && g.face[1] == MGRT_CELL_DIRICHLET);
     // a point (lane, row j) belongs to the colour of pass `odd` when (x + y + y_offset + odd) is even
-    const bool even0 = ((x + y0 + g.y0) & 1) == 0;
+    const int yg0 = y0 + g.y0; // global row of j = 0
+    const bool even0 = ((x + yg0) & 1) == 0;
     // rows strictly inside the global grid: jlo <= j < jhi; the face rows are jlo - 1 and jhi
-    const int jlo = 1 - (y0 + g.y0), jhi = g.gny - 1 - (y0 + g.y0);
+    const int jlo = 1 - yg0, jhi = g.gny - 1 - yg0;
     // -1 where the face is not Dirichlet: no row matches
     const int jdlo = g.face[2] == MGRT_CELL_DIRICHLET ? jlo - 1 : -1, jdhi = g.face[3] == MGRT_CELL_DIRICHLET ? jhi : -1;
+
+    if constexpr (IN == CORRECTED) {
+        // u += 4 * P(e) with the expressions of the interpolation kernel (bilinear weights, every
+        // product formed, zero weights included; injection on Dirichlet and Neumann cells).  The
+        // tile's fine rows read RT/2 + 2 coarse rows, loaded once per lane at x/2 and x/2 + 1.
+        constexpr int NC = RT / 2 + 2;
+        const int cbase = (yg0 >> 1) - cg.y0; // coarse row under j = 0 (floor division)
+        const int ci = xc >> 1, ci1 = min(ci + 1, cg.nx - 1);
+        R c0[NC], c1[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const long long row = cg.pitch * (long long)min(max(cbase + k, 0), cg.ny - 1);
+            c0[k] = e[ci + row];
+            c1[k] = e[ci1 + row];
+        }
+        const bool x_face = x == 0 || x == nx - 1;
+        const bool x_border = (x == 0 && (g.face[0] == MGRT_CELL_DIRICHLET || g.face[0] == MGRT_CELL_NEUMANN)) ||
+                              (x == nx - 1 && (g.face[1] == MGRT_CELL_DIRICHLET || g.face[1] == MGRT_CELL_NEUMANN));
+        const bool lo_border = g.face[2] == MGRT_CELL_DIRICHLET || g.face[2] == MGRT_CELL_NEUMANN;
+        const bool hi_border = g.face[3] == MGRT_CELL_DIRICHLET || g.face[3] == MGRT_CELL_NEUMANN;
+        const R wu = 0.5 * (xc % 2);
+        auto correct = [&](auto parity) {
+            constexpr int P = decltype(parity)::value; // parity of yg0
+#pragma unroll
+            for (int j = 0; j < RT; ++j) {
+                const int k = (j + P) >> 1; // a constant once the loop is unrolled
+                const R ww = 0.5 * ((j + P) % 2);
+                const bool border = x_face ? x_border : (j == jlo - 1 && lo_border) || (j == jhi && hi_border);
+                const R n0 = (1.0 - wu) * (1.0 - ww), n1 = (1.0 - ww) * wu, n2 = (1.0 - wu) * ww, n3 = ww * wu;
+                const R val = border ? c0[k] : c0[k] * n0 + c1[k] * n1 + c0[k + 1] * n2 + c1[k + 1] * n3;
+                u[j] = u[j] + val * 4;
+            }
+        };
+        if (yg0 & 1)
+            correct(std::integral_constant<int, 1>{});
+        else
+            correct(std::integral_constant<int, 0>{});
+    }
 
     // Tiles whose rows 1 .. RT-2 all lie strictly inside the grid (nearly all of them) need no
     // per-row class: four lane masks serve every row of every pass.
@@ -118,7 +165,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, RT>())) void k_
     else
         passes(std::false_type{});
 
-    if (lane >= H && lane < 64 - H && x < nx) {
+    const bool stores = lane >= H && lane < 64 - H && x < nx;
+    if (stores) {
         R *po = out + x + pitch * (long long)(y0 + H); // y0 + H >= 0 for every tile
 #pragma unroll
         for (int j = H; j < RT - H; ++j) {
@@ -127,50 +175,105 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, RT>())) void k_
             po += pitch;
         }
     }
+    if constexpr (RES) {
+        // the residual kernel's expressions; cells that are neither inner nor Dirichlet get 0
+        const int lo = max(jlo, first), hi = min(jhi, last + 1);
+        const int dlo = jdlo >= first ? jdlo : -1, dhi = jdhi <= last ? jdhi : -1;
+        R *pr = res + x + pitch * (long long)(y0 + H);
+#pragma unroll
+        for (int j = H; j < RT - H; ++j) {
+            const R xp = from_upper_lane(u[j]), xm = from_lower_lane(u[j]); // all lanes take part
+            const bool inner = x_inner && j >= lo && j < hi;
+            const bool dirichlet = (x_dirichlet && j >= first && j <= last) || (x_inner && (j == dlo || j == dhi));
+            const R v = inner ? b[j] - (xp + xm + u[j + 1] + u[j - 1] - 4 * u[j]) : dirichlet ? b[j] - u[j] : (R)0;
+            if (stores && j <= last)
+                *pr = v;
+            pr += pitch;
+        }
+    }
 }
 
-template <class R, int ITERS, int RT>
-mgrt_status launch2d_cols(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, hipStream_t hs)
+template <class R, int ITERS, int RT, Input IN, bool RES>
+mgrt_status launch2d_cols(const mgrt_grid *g, const mgrt_grid *cg, R *out, R *res, const R *in, const R *e, const R *f,
+                          R omega, hipStream_t hs)
 {
-    constexpr int H = 2 * ITERS;
+    constexpr int H = 2 * ITERS + (RES ? 1 : 0);
     const int ntx = (g->nx + 64 - 2 * H - 1) / (64 - 2 * H), nty = (g->ny + RT - 2 * H - 1) / (RT - 2 * H);
     const int ntiles = ntx * nty, blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 grid(blocks), block(64 * kWavesPerBlock);
-    const bool one = omega == (R)1;
-    if (one && !in)
-        k_smooth2d_cols<R, ITERS, RT, true, true><<<grid, block, 0, hs>>>(*g, in, out, f, omega, ntx, ntiles);
-    else if (one)
-        k_smooth2d_cols<R, ITERS, RT, true, false><<<grid, block, 0, hs>>>(*g, in, out, f, omega, ntx, ntiles);
-    else if (!in)
-        k_smooth2d_cols<R, ITERS, RT, false, true><<<grid, block, 0, hs>>>(*g, in, out, f, omega, ntx, ntiles);
+    if (omega == (R)1)
+        k_smooth2d_cols<R, ITERS, RT, true, IN, RES><<<grid, block, 0, hs>>>(*g, cg ? *cg : *g, in, out, f, e, res, omega, ntx, ntiles);
     else
-        k_smooth2d_cols<R, ITERS, RT, false, false><<<grid, block, 0, hs>>>(*g, in, out, f, omega, ntx, ntiles);
+        k_smooth2d_cols<R, ITERS, RT, false, IN, RES><<<grid, block, 0, hs>>>(*g, cg ? *cg : *g, in, out, f, e, res, omega, ntx, ntiles);
     MGRT_HIP(hipGetLastError());
     return MGRT_OK;
 }
 
-template <class R, int ITERS>
-mgrt_status sweep2d(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, hipStream_t hs)
+#ifdef MGRT_TUNE
+int tuned_rows(const char *name, int dflt)
 {
-    // measured on V(2,2) cycles: 16 rows from 2049^2 up, 12 rows below
-    if ((long long)g->nx * g->ny >= 1500LL * 1500LL)
-        return launch2d_cols<R, ITERS, 16>(g, out, in, f, omega, hs);
-    return launch2d_cols<R, ITERS, 12>(g, out, in, f, omega, hs);
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+#define MGRT_ROWS(name, dflt) tuned_rows(name, dflt)
+#else
+#define MGRT_ROWS(name, dflt) (dflt)
+#endif
+
+// Tile heights measured on V(2,2) cycles: 16 rows from 2049^2 up, 12 rows below; four rows more with
+// the wider halo of the residual variant.
+template <class R, int ITERS, Input IN, bool RES>
+mgrt_status sweep2d(const mgrt_grid *g, const mgrt_grid *cg, R *out, R *res, const R *in, const R *e, const R *f, R omega,
+                    hipStream_t hs)
+{
+    const bool large = (long long)g->nx * g->ny >= 1500LL * 1500LL;
+    if constexpr (RES) {
+        const int rt = MGRT_ROWS("MGRT_2D_ROWS_RES", large ? 20 : 16);
+#ifdef MGRT_TUNE
+        if (rt == 14) return launch2d_cols<R, ITERS, 14, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+        if (rt == 24) return launch2d_cols<R, ITERS, 24, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+#endif
+        if (rt == 16) return launch2d_cols<R, ITERS, 16, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+        return launch2d_cols<R, ITERS, 20, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+    } else {
+        const int rt = MGRT_ROWS("MGRT_2D_ROWS", large ? 16 : 12);
+#ifdef MGRT_TUNE
+        if (rt == 20) return launch2d_cols<R, ITERS, 20, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+#endif
+        if (rt == 12) return launch2d_cols<R, ITERS, 12, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+        return launch2d_cols<R, ITERS, 16, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+    }
+}
+
+template <class R>
+mgrt_status sweep2d_any(const mgrt_grid *g, const mgrt_grid *cg, R *out, R *res, const R *in, const R *e, const R *f,
+                        R omega, int iters, hipStream_t hs)
+{
+#define MGRT_2D(IN, RES) \
+    (iters == 1 ? sweep2d<R, 1, IN, RES>(g, cg, out, res, in, e, f, omega, hs) : sweep2d<R, 2, IN, RES>(g, cg, out, res, in, e, f, omega, hs))
+    if (e)
+        return MGRT_2D(CORRECTED, false);
+    if (res)
+        return in ? MGRT_2D(FIELD, true) : MGRT_2D(ZEROS, true);
+    return in ? MGRT_2D(FIELD, false) : MGRT_2D(ZEROS, false);
+#undef MGRT_2D
 }
 
 } // namespace
 
 namespace mgrt {
 
-mgrt_status smooth_sweep_2d(const mgrt_grid *g, float *out, const float *in, const float *f, float omega, int iters,
-                            hipStream_t hs)
+// out = S^iters(in); with res != nullptr also res = residual of out; with e != nullptr (and the
+// coarse grid cg) the input is in + 4*P(e) instead of in.  in == nullptr: a field of zeros.
+mgrt_status smooth_sweep_2d(const mgrt_grid *g, const mgrt_grid *cg, float *out, float *res, const float *in,
+                            const float *e, const float *f, float omega, int iters, hipStream_t hs)
 {
-    return iters == 1 ? sweep2d<float, 1>(g, out, in, f, omega, hs) : sweep2d<float, 2>(g, out, in, f, omega, hs);
+    return sweep2d_any<float>(g, cg, out, res, in, e, f, omega, iters, hs);
 }
-mgrt_status smooth_sweep_2d(const mgrt_grid *g, double *out, const double *in, const double *f, double omega, int iters,
-                            hipStream_t hs)
+mgrt_status smooth_sweep_2d(const mgrt_grid *g, const mgrt_grid *cg, double *out, double *res, const double *in,
+                            const double *e, const double *f, double omega, int iters, hipStream_t hs)
 {
-    return iters == 1 ? sweep2d<double, 1>(g, out, in, f, omega, hs) : sweep2d<double, 2>(g, out, in, f, omega, hs);
+    return sweep2d_any<double>(g, cg, out, res, in, e, f, omega, iters, hs);
 }
 
 } // namespace mgrt

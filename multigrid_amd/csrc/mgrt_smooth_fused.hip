@@ -397,11 +397,8 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
     if (iters != 1 && iters != 2)
         return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep: iters must be 1 or 2, got %d", iters);
     hipStream_t hs = (hipStream_t)s;
-    if (g->dim != 3) {
-        if (res)
-            return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep_residual: 3D grids only");
-        return smooth_sweep_2d(g, out, in, f, omega, iters, hs);
-    }
+    if (g->dim != 3)
+        return smooth_sweep_2d(g, nullptr, out, res, in, nullptr, f, omega, iters, hs);
     using C = Cfg<R>;
 #ifdef MGRT_TUNE
     // development only: pick a tile shape at run time
@@ -489,7 +486,50 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
                  : launch<R, 2, C::SR2, C::NW2, C::PF2>(g, out, in, f, omega, zcount, hs);
 }
 
+// out = S^iters(u + 4*P(e)): the correction feeding the post-smoother without a pass of its own.
+template <class R>
+mgrt_status correct_smooth_sweep(const mgrt_grid *fine, const mgrt_grid *coarse, R *out, const R *u, const R *e,
+                                 const R *f, R omega, int iters, int zcount, mgrt_stream s)
+{
+    if (mgrt_status st = require_init()) return st;
+    if (mgrt_status st = check_grid(fine, "mgrt_correct_smooth_sweep")) return st;
+    if (mgrt_status st = check_grid(coarse, "mgrt_correct_smooth_sweep")) return st;
+    MGRT_REQUIRE(out && u && e && f, "mgrt_correct_smooth_sweep: null field");
+    MGRT_REQUIRE(out != u && out != f && out != e, "mgrt_correct_smooth_sweep: out must not alias an input");
+    MGRT_REQUIRE(fine->dim == coarse->dim, "mgrt_correct_smooth_sweep: grids of different dimension");
+    MGRT_REQUIRE(coarse->nx == (fine->nx + 1) / 2 && coarse->gny == (fine->gny + 1) / 2,
+                 "mgrt_correct_smooth_sweep: coarse grid %dx%d is not the half of %dx%d", coarse->nx, coarse->gny, fine->nx,
+                 fine->gny);
+    MGRT_REQUIRE(zcount >= 0 && zcount <= fine->nz, "mgrt_correct_smooth_sweep: zcount %d outside [0,%d]", zcount, fine->nz);
+    if (fine->cells || coarse->cells)
+        return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: byte cell maps are not supported");
+    if (iters != 1 && iters != 2)
+        return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: iters must be 1 or 2, got %d", iters);
+    if (fine->dim != 2)
+        return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: 2D grids only");
+    // the coarse rows the fine rows interpolate from must be held, as for mgrt_correct (with an even
+    // fine extent the last row would read one coarse row too far, as the reference does)
+    const int clo = fine->y0 / 2 - coarse->y0, chi = (fine->ny - 1 + fine->y0 + 1) / 2 - coarse->y0;
+    MGRT_REQUIRE(clo >= 0 && chi < coarse->ny, "mgrt_correct_smooth_sweep: coarse slab does not hold rows %d..%d",
+                 clo + coarse->y0, chi + coarse->y0);
+    return smooth_sweep_2d(fine, coarse, out, nullptr, u, e, f, omega, iters, (hipStream_t)s);
+}
+
 } // namespace
+
+extern "C" mgrt_status mgrt_correct_smooth_sweep_f32(const mgrt_grid *fine, const mgrt_grid *coarse, float *out,
+                                                     const float *u, const float *e, const float *f, float omega,
+                                                     int iters, int zcount, mgrt_stream s)
+{
+    return correct_smooth_sweep<float>(fine, coarse, out, u, e, f, omega, iters, zcount, s);
+}
+
+extern "C" mgrt_status mgrt_correct_smooth_sweep_f64(const mgrt_grid *fine, const mgrt_grid *coarse, double *out,
+                                                     const double *u, const double *e, const double *f, double omega,
+                                                     int iters, int zcount, mgrt_stream s)
+{
+    return correct_smooth_sweep<double>(fine, coarse, out, u, e, f, omega, iters, zcount, s);
+}
 
 extern "C" mgrt_status mgrt_smooth_sweep_f32(const mgrt_grid *g, float *out, const float *in, const float *f,
                                              float omega, int iters, int zcount, mgrt_stream s)
