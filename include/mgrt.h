@@ -121,8 +121,10 @@ mgrt_status mgrt_box_cells_host(int dim, int nx, int ny, int nz, const int face[
                                               mgrt_stream s);                                      \
     /* out = S^iters(u + 4*P(e)): the results of mgrt_correct followed by mgrt_smooth_sweep, the   \
        corrected field never written.  Replaces correct_residual followed by the post-smoothing    \
-       smoother_iterate (multigridsolver2D.cpp:77,92).  2D analytic-box grids only                 \
-       (MGRT_E_UNSUPPORTED otherwise: call the two kernels).  out must not alias an input. */      \
+       smoother_iterate (multigridsolver2D.cpp:77,92, multigridsolver3D.cpp:70,77).  Analytic-box  \
+       grids with odd extents; in 3D only 4-byte elements, iters == 2, an even y0 and more than    \
+       300*300 columns (MGRT_E_UNSUPPORTED otherwise: call the two kernels).  out must not alias   \
+       an input. */                                                                                \
     mgrt_status mgrt_correct_smooth_sweep##S(const mgrt_grid *fine, const mgrt_grid *coarse,       \
                                              R *out, const R *u, const R *e, const R *f, R omega,  \
                                              int iters, int zcount, mgrt_stream s);                \

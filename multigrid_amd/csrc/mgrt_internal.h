@@ -66,6 +66,14 @@ mgrt_status bottom_cycle(int dim, int nlev, const int *nx, const int *ny, const 
                          double *u, const double *u_in, const double *f, double omega, int a1, int a2, int v,
                          hipStream_t hs);
 
+// Whether mgrt_correct_smooth_sweep has a 3D kernel for this level: the plan asks before it drops the
+// separate correction.
+inline bool correct_sweep_3d_supported(const mgrt_grid *g, size_t elem, int iters)
+{
+    return g->dim == 3 && elem == 4 && iters == 2 && !g->cells && g->y0 % 2 == 0 && g->nx % 2 == 1 && g->gny % 2 == 1 &&
+           g->nz % 2 == 1 && g->nz >= 5 && !latency_bound_level(*g);
+}
+
 // out = S^iters(in) on a 2D analytic-box grid, iters 1 or 2 (mgrt_smooth2d.hip); in may be null.
 // res (optional) receives the residual of out; e with its coarse grid cg (optional) makes the input
 // in + 4*P(e).

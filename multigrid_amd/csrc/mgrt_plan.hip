@@ -183,11 +183,15 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
     }
     // On bandwidth-bound levels the last pre-smoothing sweep carries the residual pass along
     // (4-byte elements: with 8-byte ones the narrower strips make it slower than the two kernels).
-    // In 2D every fused level does, and the last correction goes into the first post-smoothing sweep.
+    // In 2D every fused level does.  The last correction goes into the first post-smoothing sweep
+    // where a kernel for that exists: every 2D level, and in 3D the bandwidth-bound levels in single
+    // precision when that sweep does two iterations.
     const bool res_in_sweep =
         n1 > 0 && v > 0 && recurses(L.g) &&
         (L.g.dim == 2 || (sizeof(R) == 4 && L.g.dim == 3 && !latency_bound_level(L.g) && !p->fuse_rr));
-    const bool correct_in_sweep = L.g.dim == 2 && n2 > 0 && a2 > 0 && v > 0 && recurses(L.g);
+    const bool correct_in_sweep =
+        n2 > 0 && a2 > 0 && v > 0 && recurses(L.g) &&
+        (L.g.dim == 2 || (!p->fuse_rr && correct_sweep_3d_supported(&L.g, sizeof(R), n2 < a2 ? 2 : 1)));
     if (a1 > 0)
         if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a1, n1, res_in_sweep ? (R *)L.r : nullptr, u_is_zero))
             return st;

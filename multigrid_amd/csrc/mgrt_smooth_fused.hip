@@ -46,12 +46,34 @@ constexpr int kWave = 64;
 // res = f - A out on inner points, f - out on Dirichlet points, 0 elsewhere (residual_kernel,
 // mg_1.cl:46-53,111-133, with the cells it leaves unwritten set to 0).  It costs one more ring of
 // halo and two more planes in the rings, and saves a separate pass over out and f.
-template <class R, int ITERS, int SR, int NW, int PD, bool OMEGA1, bool RES>
+//
+// COR makes the input in + 4*P(e) instead of in: the coarse-grid correction (residual_correct_kernel,
+// mg_1.cl:200-233) applied to every plane on its way from the prefetch registers into the ring, so
+// that the post-smoother needs no corrected field in memory.  A lane keeps the coarse values its SR
+// rows interpolate from (SR/2+1 coarse rows at x/2 and x/2+1) for the two coarse planes around the
+// fine plane; every second step one coarse plane is prefetched along with the fine one.  The tile's
+// first row must be even (globally), so that which rows and planes sit between coarse points is
+// known at compile time and the eight trilinear weights are per-lane constants.
+struct CoarseField {
+    const void *e;
+    long long pitch, slab;
+    int nx, ny, nz, y0;
+};
+
+// dot(real4, real4) as the reference evaluates it: left to right in R
+template <class R> __device__ __forceinline__ R dot4(R a0, R a1, R a2, R a3, R b0, R b1, R b2, R b3)
+{
+    return a0 * b0 + a1 * b1 + a2 * b2 + a3 * b3;
+}
+
+template <class R, int ITERS, int SR, int NW, int PD, bool OMEGA1, bool RES, bool COR = false>
 __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const R *__restrict__ in,
                                                               R *__restrict__ out, const R *__restrict__ f,
-                                                              R *__restrict__ res, R omega, int zcount, int ntx)
+                                                              R *__restrict__ res, R omega, int zcount, int ntx,
+                                                              CoarseField cf)
 {
     static_assert(SR % 2 == 0, "rows are handled in pairs");
+    static_assert(!COR || (PD == 2 && !RES), "the corrected input is built for a prefetch depth of two planes");
     constexpr int NP = 2 * ITERS, J = SR / 2;
     constexpr int H = NP + (RES ? 1 : 0);  // halo rings consumed
     constexpr int DR = NP + 2;             // ring depth of the residual pass
@@ -131,6 +153,47 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
 
     const long long slab = g.slab;
     const int zlast = g.nz - 1;
+
+    // ---- coarse-grid correction: offsets, weights, the two coarse planes in registers ----------
+    constexpr int NCR = SR / 2 + 1; // coarse rows under SR fine rows that start on an even row
+    const R *eb = (const R *)cf.e;
+    const int klast = cf.nz - 1;
+    const unsigned cplane_bytes = COR ? (unsigned)(cf.pitch * (long long)cf.ny * (long long)sizeof(R)) : 0u;
+    unsigned eoff[NCR][2];
+    R Ea[NCR][2], Eb[NCR][2], pe[NCR][2]; // coarse planes z/2 and z/2+1 (clamped), and the prefetched one
+    R wa1 = 0, wa2 = 0, wa4 = 0, wu1 = 0, wu2 = 0, wu4 = 0;
+    if constexpr (COR) {
+        // as the interpolation kernel: index x/2 and, clamped to the array, x/2 + 1; likewise in y
+        const int xc = x < 0 ? 0 : (x < g.nx ? x : g.nx - 1);
+        const int ci = xc / 2, ci1 = ci + 1 < cf.nx ? ci + 1 : ci;
+        const int cj0 = ((y0 + g.y0) >> 1) - cf.y0;
+#pragma unroll
+        for (int m = 0; m < NCR; ++m) {
+            const int cj = cj0 + m < 0 ? 0 : (cj0 + m < cf.ny ? cj0 + m : cf.ny - 1);
+            eoff[m][0] = ((unsigned)ci + (unsigned)cf.pitch * (unsigned)cj) * (unsigned)sizeof(R);
+            eoff[m][1] = ((unsigned)ci1 + (unsigned)cf.pitch * (unsigned)cj) * (unsigned)sizeof(R);
+        }
+        // weights (1-wu)*c and wu*c for c = 1, 1/2, 1/4, all exact: wu = 0.5 * (x % 2)
+        const R wu = 0.5 * (xc % 2);
+        wa1 = 1.0 - wu, wa2 = 0.5 * (1.0 - wu), wa4 = 0.25 * (1.0 - wu);
+        wu1 = wu, wu2 = 0.5 * wu, wu4 = 0.25 * wu;
+        const desc_t r0 = plane_desc(eb, cplane_bytes), r1 = plane_desc(eb + cf.slab * (klast < 1 ? klast : 1), cplane_bytes);
+#pragma unroll
+        for (int m = 0; m < NCR; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                buf_load_hidden(Eb[m][q], r0, eoff[m][q]); // becomes plane z/2 at step 0
+                buf_load_hidden(pe[m][q], r1, eoff[m][q]);
+                Ea[m][q] = 0;
+            }
+    }
+    auto pin_coarse = [&](R(&a)[NCR][2]) { // orders every later use of `a` after the wait before it
+        if constexpr (COR) {
+#pragma unroll
+            for (int m = 0; m < NCR; ++m)
+                asm volatile("" : "+v"(a[m][0]), "+v"(a[m][1]));
+        }
+    };
     R pu[PD][SR], pf[PD][SR];
 #pragma unroll
     for (int k = 0; k < PD; ++k) {
@@ -146,6 +209,8 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
 #pragma unroll
         for (int k = 0; k < PD; ++k)
             wait_slot<0>(pu[k], pf[k]);
+        pin_coarse(pe);
+        pin_coarse(Eb);
     };
     drain0(); // the loop below starts from landed registers (see `drain`)
 
@@ -164,9 +229,11 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
         desc_t d_in = plane_desc(inb + slab * (i0 + PD), in_bytes), d_f = plane_desc(f + slab * (i0 + PD), plane_bytes);
         desc_t d_out = plane_desc(out + slab * (i0 - NP), plane_bytes);
         desc_t d_res = plane_desc(RES ? res + slab * (i0 - DR) : out, plane_bytes);
+        // coarse plane prefetched at the group's first (even) step: the upper one of fine plane i0 + PD
+        desc_t d_e = plane_desc(COR ? eb + cf.slab * ((i0 + PD) / 2 + 1) : eb, cplane_bytes);
         const unsigned long long slab_bytes = (unsigned long long)slab * sizeof(R);
-        auto advance = [&](desc_t &d) {
-            const unsigned long long a = (((unsigned long long)(unsigned)d.y << 32) | (unsigned)d.x) + slab_bytes;
+        auto advance = [&](desc_t &d, unsigned long long by) {
+            const unsigned long long a = (((unsigned long long)(unsigned)d.y << 32) | (unsigned)d.x) + by;
             d.x = (int)(unsigned)a;
             d.y = (int)(unsigned)(a >> 32); // addresses stay below 2^48: the upper half of word 1 stays 0
         };
@@ -180,13 +247,52 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                 // In a fast group every step issues 2*SR loads then kStores stores, so the slot's
                 // loads have kStores stores and PD-1 whole steps behind them; elsewhere steps may
                 // skip their stores, so wait for everything.
-                if (FAST)
-                    wait_slot<kYounger>(pu[ps], pf[ps]);
-                else
+                // With COR the slots of even planes carry the 2*NCR coarse loads as well, so an odd
+                // plane's slot has that many more operations behind it.
+                constexpr int kYoungerOdd = kYounger + (COR ? 2 * NCR : 0);
+                static_assert(!COR || kYoungerOdd + 2 * SR + 2 * NCR < 64, "too many vector-memory operations in flight");
+                if (!FAST)
                     wait_slot<0>(pu[ps], pf[ps]);
+                else if (u & 1) // folds once the loop is unrolled
+                    wait_slot<kYoungerOdd>(pu[ps], pf[ps]);
+                else
+                    wait_slot<kYounger>(pu[ps], pf[ps]);
+                R cor[SR];
+                if constexpr (COR) {
+                    const int pz = u & 1; // parity of plane i
+                    if (pz == 0) { // planes (i/2, i/2 + 1): the upper one has just landed
+                        pin_coarse(pe);
+#pragma unroll
+                        for (int m = 0; m < NCR; ++m)
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                Ea[m][q] = Eb[m][q];
+                                Eb[m][q] = pe[m][q];
+                            }
+                        pin_coarse(Eb); // real copies, made before pe is requested again
+                    }
+                    const int zcls = FAST ? (int)MGRT_CELL_INNER
+                                          : (i == 0 ? g.face[4] : (i == zlast ? g.face[5] : (int)MGRT_CELL_INNER));
+#pragma unroll
+                    for (int r = 0; r < SR; ++r) {
+                        const int py = r & 1, m = r >> 1;
+                        // c1 = (1-ww)(1-wv), c2 = ww(1-wv), c3 = (1-ww)wv, c4 = ww*wv with ww = py/2, wv = pz/2
+                        const R n10 = py + pz == 0 ? wa1 : (py + pz == 1 ? wa2 : wa4);
+                        const R n11 = py + pz == 0 ? wu1 : (py + pz == 1 ? wu2 : wu4);
+                        const R n12 = py == 0 ? (R)0 : (pz == 0 ? wa2 : wa4), n13 = py == 0 ? (R)0 : (pz == 0 ? wu2 : wu4);
+                        const R n20 = pz == 0 ? (R)0 : (py == 0 ? wa2 : wa4), n21 = pz == 0 ? (R)0 : (py == 0 ? wu2 : wu4);
+                        const R n22 = py + pz == 2 ? wa4 : (R)0, n23 = py + pz == 2 ? wu4 : (R)0;
+                        const R val = dot4<R>(Ea[m][0], Ea[m][1], Ea[m + 1][0], Ea[m + 1][1], n10, n11, n12, n13) +
+                                      dot4<R>(Eb[m][0], Eb[m][1], Eb[m + 1][0], Eb[m + 1][1], n20, n21, n22, n23);
+                        const int cls = rowcls[r] >= 0 ? rowcls[r] : zcls;
+                        const bool border = cls == MGRT_CELL_DIRICHLET || cls == MGRT_CELL_NEUMANN;
+                        cor[r] = (border ? Ea[m][0] : val) * 4;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
-                    const R a0 = pu[ps][2 * j], a1 = pu[ps][2 * j + 1];
+                    const R a0 = COR ? pu[ps][2 * j] + cor[COR ? 2 * j : 0] : pu[ps][2 * j];
+                    const R a1 = COR ? pu[ps][2 * j + 1] + cor[COR ? 2 * j + 1 : 0] : pu[ps][2 * j + 1];
                     const R b0 = pf[ps][2 * j], b1 = pf[ps][2 * j + 1];
                     C[0][PH(0)][j] = s0 ? a1 : a0;
                     C[1][PH(0)][j] = s0 ? a0 : a1;
@@ -207,6 +313,17 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                     for (int r = 0; r < SR; ++r) {
                         buf_load_hidden(pu[ps][r], ru, off[r]);
                         buf_load_hidden(pf[ps][r], rf, off[r]);
+                    }
+                    if constexpr (COR) {
+                        if ((u & 1) == 0) { // the upper coarse plane of fine plane i + PD
+                            const int kn = (zn < zlast ? zn : zlast) / 2 + 1;
+                            const desc_t re = FAST ? d_e : plane_desc(eb + cf.slab * (kn < klast ? kn : klast), cplane_bytes);
+#pragma unroll
+                            for (int m = 0; m < NCR; ++m) {
+                                buf_load_hidden(pe[m][0], re, eoff[m][0]);
+                                buf_load_hidden(pe[m][1], re, eoff[m][1]);
+                            }
+                        }
                     }
                 }
                 // ---- publish, for every pass, the strip's first and last row of the colour it
@@ -310,9 +427,11 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                 }
 #undef PH
                 if (FAST) {
-                    advance(d_in), advance(d_f), advance(d_out);
+                    advance(d_in, slab_bytes), advance(d_f, slab_bytes), advance(d_out, slab_bytes);
                     if (RES)
-                        advance(d_res);
+                        advance(d_res, slab_bytes);
+                    if (COR && (u & 1) == 0)
+                        advance(d_e, (unsigned long long)cf.slab * sizeof(R));
                 }
             }
         }
@@ -326,12 +445,14 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
 #pragma unroll
         for (int k = 0; k < PD; ++k)
             wait_slot<0>(pu[k], pf[k]);
+        pin_coarse(pe);
     };
     // first step of a group: deepest plane (i0 - NP, or i0 - DR with the residual pass) >= 1; last
     // step: shallowest plane i0 + UN - 2 below the top face and zlim, prefetched plane
     // i0 + UN - 1 + PD <= zlast
     auto is_fast = [&](int i0) {
-        return i0 >= (RES ? DR : NP) + 1 && i0 + UN - 2 < zlim && i0 + UN - 2 < zlast && i0 + UN - 1 + PD <= zlast;
+        return i0 >= (RES ? DR : NP) + 1 && i0 + UN - 2 < zlim && i0 + UN - 2 < zlast &&
+               i0 + UN - 1 + PD + (COR ? 2 : 0) <= zlast; // COR: the coarse plane above the prefetched fine one exists
     };
     // The fast groups run in a loop of their own: with a single path through the loop body the
     // register allocator keeps every ring and prefetch register in place across the back edge
@@ -352,18 +473,25 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
     }
 }
 
-template <class R, int ITERS, int SR, int NW, int PD, bool RES = false>
+template <class R, int ITERS, int SR, int NW, int PD, bool RES = false, bool COR = false>
 mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, int zcount, hipStream_t hs,
-                   R *res = nullptr)
+                   R *res = nullptr, const mgrt_grid *cg = nullptr, const R *e = nullptr)
 {
     constexpr int H = 2 * ITERS + (RES ? 1 : 0), OX = kWave - 2 * H, OY = NW * SR - 2 * H;
     static_assert(OY > 0, "tile has no interior");
+    // every strip starts on an even row of its slab (the corrected input relies on it)
+    static_assert(!COR || (OY % 2 == 0 && H % 2 == 0), "strips must start on even rows");
     const int ntx = (g->nx + OX - 1) / OX, nty = (g->ny + OY - 1) / OY;
     const dim3 grid(ntx * nty);
+    CoarseField cf = {};
+    if (COR) {
+        cf.e = e, cf.pitch = cg->pitch, cf.slab = cg->slab;
+        cf.nx = cg->nx, cf.ny = cg->ny, cf.nz = cg->nz, cf.y0 = cg->y0;
+    }
     if (omega == (R)1)
-        k_smooth3d_fused<R, ITERS, SR, NW, PD, true, RES><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx);
+        k_smooth3d_fused<R, ITERS, SR, NW, PD, true, RES, COR><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
     else
-        k_smooth3d_fused<R, ITERS, SR, NW, PD, false, RES><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx);
+        k_smooth3d_fused<R, ITERS, SR, NW, PD, false, RES, COR><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
     MGRT_HIP(hipGetLastError());
     return MGRT_OK;
 }
@@ -505,13 +633,26 @@ mgrt_status correct_smooth_sweep(const mgrt_grid *fine, const mgrt_grid *coarse,
         return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: byte cell maps are not supported");
     if (iters != 1 && iters != 2)
         return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: iters must be 1 or 2, got %d", iters);
-    if (fine->dim != 2)
-        return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: 2D grids only");
     // the coarse rows the fine rows interpolate from must be held, as for mgrt_correct (with an even
     // fine extent the last row would read one coarse row too far, as the reference does)
     const int clo = fine->y0 / 2 - coarse->y0, chi = (fine->ny - 1 + fine->y0 + 1) / 2 - coarse->y0;
     MGRT_REQUIRE(clo >= 0 && chi < coarse->ny, "mgrt_correct_smooth_sweep: coarse slab does not hold rows %d..%d",
                  clo + coarse->y0, chi + coarse->y0);
+    if (fine->dim == 3) {
+        MGRT_REQUIRE(coarse->nz == (fine->nz + 1) / 2, "mgrt_correct_smooth_sweep: coarse grid has %d planes for %d",
+                     coarse->nz, fine->nz);
+        if (!correct_sweep_3d_supported(fine, sizeof(R), iters))
+            return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: in 3D, 4-byte elements, iters == 2, odd extents, an "
+                                            "even slab offset and more than 300^2 columns only");
+        MGRT_REQUIRE(fine->slab < (1LL << 30) && coarse->slab < (1LL << 30),
+                     "mgrt_correct_smooth_sweep: plane too large for 32-bit in-plane offsets");
+        if constexpr (sizeof(R) == 4) {
+            using C = Cfg<R>;
+            return launch<R, 2, C::SR2, C::NW2, C::PF2, false, true>(fine, out, u, f, omega, zcount, (hipStream_t)s, nullptr,
+                                                                     coarse, e);
+        }
+        return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: no 3D kernel for this element size");
+    }
     return smooth_sweep_2d(fine, coarse, out, nullptr, u, e, f, omega, iters, (hipStream_t)s);
 }
 

@@ -340,6 +340,65 @@ def test_fused_sweep_2d_with_residual_and_with_correction(dev, mgo, dt, shape):
                     assert bits_equal(outs[h + 1:-h - 1].cpu().numpy(), ref[y0:y1]), (shape, faces, iters, "corrected slab")
 
 
+@pytest.mark.parametrize("shape", [(9, 321, 305), (5, 331, 303), (33, 303, 513), (17, 611, 309)],
+                         ids=lambda s: "x".join(map(str, s[::-1])))
+def test_fused_sweep_3d_with_correction(dev, mgo, shape):
+    """3D, wide planes: the sweep whose input is u + 4*P(e) against the correction kernel followed by
+    the sweep (both checked against the oracle elsewhere) and, for the smallest case, against the
+    oracle itself; whole grids, both z ranges, a y-slab at an even offset; and the cases the kernel
+    declines."""
+    import torch
+    from multigrid_amd import _lib as L
+    torch.manual_seed(abs(hash(shape)) % 2**31)
+    cs = tuple((n + 1) // 2 for n in shape)
+    # Where an outer face meets the top z face the reference (and the oracle) multiply values past
+    # the end of the coarse array by the zero weights: the last case is compared between the GPU
+    # paths only.
+    for faces in ((2,) * 6, (2, 3, 3, 2, 2, 3), (3, 3, 2, 2, 1, 2), (1, 2, 1, 3, 3, 2)):
+        g, gc = L.grid(shape, faces=faces), L.grid(cs, faces=faces)
+        u = torch.randn(shape, device=dev)
+        f = torch.randn(shape, device=dev)
+        e = torch.randn(cs, device=dev)
+        for omega, zc in ((1.0, None), (0.8, (shape[0] + 1) // 2)):
+            c = torch.empty_like(u)
+            L.correct(g, gc, c, u, e)
+            want = torch.empty_like(u)
+            L.smooth_sweep(g, want, c, f, omega, 2, zc)
+            got = torch.full_like(u, 5.0)
+            L.correct_smooth_sweep(g, gc, got, u, e, f, omega, 2, zc)
+            assert torch.equal(got.view(torch.uint8), want.view(torch.uint8)), (shape, faces, omega, zc)
+        if shape[0] <= 9 and faces[0] != 1:
+            cell = mgo.box_cells(shape, faces)
+            ref = np.empty(shape, np.float32)
+            mgo.correct(cell, ref, u.cpu().numpy(), e.cpu().numpy())
+            fn = f.cpu().numpy()
+            for _ in range(2):
+                for odd in (0, 1):
+                    mgo.smooth_pass(cell, ref, fn, np.float32(0.8), odd, (shape[0] + 1) // 2)
+            assert bits_equal(got.cpu().numpy(), ref), (shape, faces, "oracle")
+        # y-slab at an even offset with its halo of 4 rows
+        y0, y1 = 12, shape[1] - 10
+        lo, hi = y0 - 4, y1 + 4
+        us, fs = u[:, lo:hi].contiguous(), f[:, lo:hi].contiguous()
+        clo, chi = lo // 2, min(hi // 2 + 1, cs[1])
+        es = e[:, clo:chi].contiguous()
+        gs = L.grid(tuple(us.shape), faces=faces, y0=lo, gny=shape[1])
+        gcs = L.grid(tuple(es.shape), faces=faces, y0=clo, gny=cs[1])
+        outs = torch.empty_like(us)
+        L.correct_smooth_sweep(gs, gcs, outs, us, es, fs, 0.8, 2, (shape[0] + 1) // 2)
+        assert torch.equal(outs[:, 4:-4], want[:, y0:y1]), (shape, faces, "slab")
+    # declined: one iteration, double precision, narrow planes
+    with pytest.raises(L.MgrtError):
+        L.correct_smooth_sweep(g, gc, got, u, e, f, 1.0, 1)
+    with pytest.raises(L.MgrtError):
+        L.correct_smooth_sweep(g, gc, got.double(), u.double(), e.double(), f.double(), 1.0, 2)
+    small = (9, 33, 65)
+    gsm, gcsm = L.grid(small), L.grid(tuple((n + 1) // 2 for n in small))
+    z = torch.zeros(small, device=dev)
+    with pytest.raises(L.MgrtError):
+        L.correct_smooth_sweep(gsm, gcsm, torch.empty_like(z), z, torch.zeros((5, 17, 33), device=dev), z, 1.0, 2)
+
+
 def test_fused_sweep_on_a_slab(dev):
     """Rows of a y-slab (odd global offset, so the colours are shifted) equal the whole-grid rows
     wherever the halo of 2*iters rows was available."""

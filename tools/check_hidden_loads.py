@@ -5,8 +5,8 @@ the kernel's own s_waitcnt.  The source guarantees this everywhere except inside
 (fast) time loop, where it depends on the register allocator not copying the prefetch registers.
 This script compiles the file to assembly and fails if, inside any depth-2 loop of a
 k_smooth3d_fused kernel, a compiler-generated instruction reads a register that an asm load in
-that loop writes, other than after an asm wait that follows the load... approximated as: no plain
-register copy (v_mov / v_accvgpr / scratch) of such a register anywhere in the loop.
+that loop writes before a wait has retired that load (the counter is modelled: operations retire
+in issue order, vmcnt(N) leaves the youngest N in flight).
 
 Usage: tools/check_hidden_loads.py [hipcc flags...]   (exit status 1 on a finding)"""
 import os
@@ -42,25 +42,44 @@ def main():
     loop_lines = []
 
     def flush():
+        """Replays the loop body twice (the second time with the operations the first left in flight)
+        against a model of the vector-memory counter: operations retire in issue order, a wait with
+        vmcnt(N) retires all but the youngest N.  Any instruction outside the asm blocks that names a
+        register whose asm load has not retired yet is a finding."""
         nonlocal loop_lines, loops
         if not loop_lines:
             return
         loops += 1
-        dests = set()
-        for asm, line in loop_lines:
-            m = re.match(r"\s*buffer_load_dword(?:x2)?\s+(\S+),", line)
-            if asm and m:
-                dests |= regs(m.group(1))
-        for asm, line in loop_lines:
-            if asm:
-                continue
-            m = re.match(r"\s*(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32|scratch_store\S*)\s+(.*)", line)
-            if not m:
-                continue
-            ops = [o.strip() for o in m.group(2).split(",")]
-            srcs = set().union(*[regs(o) for o in ops[1:]]) if len(ops) > 1 else set()
-            if srcs & dests:
-                bad.append((kernel, line.strip()))
+        queue, pending, seen = [], set(), set()
+        for _ in range(2):
+            for asm, line in loop_lines:
+                text_ = line.split(";")[0].strip()
+                if not text_ or text_.endswith(":") or text_.startswith("."):
+                    continue
+                op = text_.split()[0]
+                m = re.match(r"s_waitcnt\s+(.*)", text_)
+                if m:
+                    n = re.search(r"vmcnt\((\d+)\)", m.group(1))
+                    if n:
+                        while len(queue) > int(n.group(1)):
+                            pending -= queue.pop(0)
+                    continue
+                is_vmem = op.startswith(("buffer_", "global_", "flat_", "scratch_"))
+                if asm:
+                    if is_vmem:
+                        m = re.match(r"buffer_load_dword(?:x2)?\s+(\S+),", text_)
+                        d = regs(m.group(1)) if m else set()
+                        queue.append(d)
+                        pending |= d
+                    continue
+                named = set()
+                for tok in re.findall(r"v\[\d+:\d+\]|v\d+", text_):
+                    named |= regs(tok)
+                if named & pending and (kernel, text_) not in seen:
+                    seen.add((kernel, text_))
+                    bad.append((kernel, text_))
+                if is_vmem:
+                    queue.append(set())
         loop_lines = []
 
     for line in text:
@@ -111,7 +130,7 @@ def main():
         print("check_hidden_loads: found %d kernels, %d inner loops -- the audit did not run" % (nk, loops))
         return 1
     for k, l in bad:
-        print("check_hidden_loads: %s: copy of a register with a hidden load pending: %s" % (k[:70], l))
+        print("check_hidden_loads: %s: use of a register with a hidden load pending: %s" % (k[:70], l))
     print("check_hidden_loads: %d kernels, %d inner loops, %d findings" % (nk, loops, len(bad)))
     return 1 if bad else 0
 

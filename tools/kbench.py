@@ -62,6 +62,10 @@ def main():
     timeit("residual_restrict", lambda: L.residual_restrict(g, gc, rc, u, f), (2 * N + Nc) * w)
     timeit("restrict", lambda: L.restrict(g, gc, rc, r), (N + Nc) * w)
     timeit("correct (in place)", lambda: L.correct(g, gc, u, u, e), (2 * N + Nc) * w)
+    try:
+        timeit("correct+smooth_sweep x2", lambda: L.correct_smooth_sweep(g, gc, o, u, e, f, 1.0, 2), (3 * N + Nc) * w)
+    except L.MgrtError as err:
+        print("correct+smooth_sweep x2: %s" % err)
     timeit("prolong", lambda: L.prolong(g, gc, o, e), (N + Nc) * w)
     timeit("sumsq", lambda: L.sumsq(g, u, n2), N * w)
 
