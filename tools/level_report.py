@@ -31,9 +31,14 @@ def main():
     rows.sort()
     # the cycles end with the sweep that follows the last correction; what bench.py launches after
     # that (its timing loop over the dominant kernel) is not part of a cycle
-    last = max((i for i, r in enumerate(rows) if "k_interp3d_v" in r[2]), default=None)
+    # (on bandwidth-bound levels that sweep applies the correction itself: last template argument)
+    def corrects(name):
+        m = re.search(r"k_smooth3d_fused<([^>]*)>", name)
+        return bool(m) and m.group(1).split(",")[-1].strip() == "true"
+    last = max((i for i, r in enumerate(rows) if "k_interp3d_v" in r[2] or corrects(r[2])), default=None)
     if last is not None:
-        end = next((i for i in range(last + 1, len(rows)) if "k_smooth3d_fused" in rows[i][2]), len(rows) - 1)
+        end = last if corrects(rows[last][2]) else next(
+            (i for i in range(last + 1, len(rows)) if "k_smooth3d_fused" in rows[i][2]), len(rows) - 1)
         rows = rows[:end + 1]
     agg = defaultdict(list)
     level = 0
@@ -44,9 +49,11 @@ def main():
         k, targs = m.group(1), [a.strip() for a in m.group(2).split(",")]
         dur = (t1 - t0) * 1e-3
         if k == "k_smooth3d_fused":
-            res = targs[-1] == "true"
-            fam = "sweep x%s%s" % (targs[1], " + residual" if res else "")
-            byts = (4 if res else 3) * pts[level] * w
+            res, cor = targs[6] == "true", targs[7] == "true"
+            if cor:
+                level -= 1
+            fam = "%ssweep x%s%s" % ("correct + " if cor else "", targs[1], " + residual" if res else "")
+            byts = (4 if res else 3) * pts[level] * w + (pts[level + 1] * w if cor else 0)
         elif k == "k_residual3d_v":
             if targs[-1] == "true":     # with the norm: the history between cycles, level 0
                 agg[(0, "residual + norm (history)", 3 * pts[0] * w)].append(dur)

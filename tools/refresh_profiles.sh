@@ -1,0 +1,29 @@
+#!/bin/bash
+# Regenerates the artefacts kept under profiles/ on a GPU box, into gpurun_out/<tag>/: the bench line
+# alone and under rocprofv3 --kernel-trace --stats, the per-level report, the kernel microbenchmark,
+# separate FETCH_SIZE / WRITE_SIZE passes over it (-> pmc_traffic.json), the other configurations and
+# the solve to tolerance.  Every GPU step runs under its own time limit; the script stops at the
+# first failure.
+# Usage: tools/refresh_profiles.sh <tag>
+set -u
+tag=$1
+root=$GRAFT_REPO_ROOT
+out=$root/gpurun_out/$tag
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+cd "$root" || exit 1
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 > "$out/bench.json" 2> "$out/bench.err" || exit 1
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python3 "$root/bench.py" --steps 20 --warmup 3 > "$out/bench_under_rocprof.json" 2> "$out/rocprof.err" || exit 1
+cd "$root" || exit 1
+cp "$out"/trace/bench_kernel_stats.csv "$out/bench_kernel_stats.csv" || exit 1
+python3 tools/trace_summary.py "$out/trace" > "$out/bench_kernel_trace_summary.txt" || exit 1
+python3 tools/level_report.py "$out/trace" 513 4 > "$out/per_level.txt" || exit 1
+timeout -k 10 200 python3 tools/kbench.py > "$out/kbench513.txt" 2>&1 || exit 1
+bash tools/pmc.sh "$out/pmc" fetch,write || exit 1
+python3 tools/pmc_summary.py "$out/pmc" > "$out/pmc_fetch_write_kbench513.txt" || exit 1
+python3 tools/pmc_traffic.py "$out/pmc" 513 f32 "$out/pmc_traffic.json" || exit 1
+timeout -k 10 400 python3 tools/bench_configs.py > "$out/configs.txt" 2> "$out/configs.err" || exit 1
+timeout -k 10 400 python3 tools/solve_to_tol.py > "$out/solve_to_tolerance.txt" 2>&1 || exit 1
+rm -rf "$out/trace"/*.db "$out/pmc"/*/*.db
+echo refreshed
