@@ -47,7 +47,7 @@ enum Input { FIELD, ZEROS, CORRECTED };
 // RES: also r = residual of `out`, which takes one more halo ring (the residual of a point reads
 // the final values of its four neighbours).
 template <class R, int ITERS, int RT, bool OMEGA1, Input IN, bool RES>
-__global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN == CORRECTED ? RT + 4 : 0)>())) void k_smooth2d_cols(
+__global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN == CORRECTED ? RT + 8 : 0)>())) void k_smooth2d_cols(
     mgrt_grid g, mgrt_grid cg, const R *__restrict__ in, R *__restrict__ out, const R *__restrict__ f,
     const R *__restrict__ e, R *__restrict__ res, R omega, int ntx, int ntiles)
 {
@@ -220,28 +220,28 @@ int tuned_rows(const char *name, int dflt)
 #define MGRT_ROWS(name, dflt) (dflt)
 #endif
 
-// Tile heights measured on V(2,2) cycles: 16 rows from 2049^2 up, 12 rows below; four rows more with
-// the wider halo of the residual variant.
+// Tile heights measured on V(2,2) cycles: 20 rows from 2049^2 up; below, 12 rows, or 14 with the
+// wider halo of the residual variant.
 template <class R, int ITERS, Input IN, bool RES>
 mgrt_status sweep2d(const mgrt_grid *g, const mgrt_grid *cg, R *out, R *res, const R *in, const R *e, const R *f, R omega,
                     hipStream_t hs)
 {
     const bool large = (long long)g->nx * g->ny >= 1500LL * 1500LL;
     if constexpr (RES) {
-        const int rt = MGRT_ROWS("MGRT_2D_ROWS_RES", large ? 20 : 16);
+        const int rt = MGRT_ROWS("MGRT_2D_ROWS_RES", large ? 20 : 14);
 #ifdef MGRT_TUNE
-        if (rt == 14) return launch2d_cols<R, ITERS, 14, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+        if (rt == 16) return launch2d_cols<R, ITERS, 16, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
         if (rt == 24) return launch2d_cols<R, ITERS, 24, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
 #endif
-        if (rt == 16) return launch2d_cols<R, ITERS, 16, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+        if (rt == 14) return launch2d_cols<R, ITERS, 14, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
         return launch2d_cols<R, ITERS, 20, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
     } else {
-        const int rt = MGRT_ROWS("MGRT_2D_ROWS", large ? 16 : 12);
+        const int rt = MGRT_ROWS("MGRT_2D_ROWS", large ? 20 : 12);
 #ifdef MGRT_TUNE
-        if (rt == 20) return launch2d_cols<R, ITERS, 20, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+        if (rt == 16) return launch2d_cols<R, ITERS, 16, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
 #endif
         if (rt == 12) return launch2d_cols<R, ITERS, 12, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
-        return launch2d_cols<R, ITERS, 16, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+        return launch2d_cols<R, ITERS, 20, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
     }
 }
 

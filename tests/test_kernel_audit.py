@@ -19,3 +19,29 @@ def test_fused_smoother_has_no_copies_of_inflight_registers():
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert " 0 findings" in p.stdout
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not installed")
+def test_2d_tile_kernels_do_not_spill(tmp_path):
+    """The 2D smoother keeps a whole tile per wave in registers; a variant that spilled would move
+    it through scratch memory.  The code-object metadata must show no private segment and no
+    spilled scalar registers for any k_smooth2d_cols instantiation."""
+    out = tmp_path / "smooth2d.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                    "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", str(out),
+                    os.path.join(ROOT, "multigrid_amd", "csrc", "mgrt_smooth2d.hip")],
+                   check=True, capture_output=True, timeout=900)
+    import re
+    name, seen, bad = None, 0, []
+    for line in out.read_text().splitlines():
+        m = re.match(r"\s+\.name:\s+(\S*k_smooth2d_cols\S*)", line)
+        if m:
+            name = m.group(1)
+            seen += 1
+        m = re.match(r"\s+\.(private_segment_fixed_size|sgpr_spill_count|vgpr_spill_count):\s+(\d+)", line)
+        if m and name and int(m.group(2)) > 0:
+            bad.append((name, m.group(1), m.group(2)))
+        if re.match(r"\s+\.wavefront_size:", line):
+            name = None
+    assert seen >= 16, "no k_smooth2d_cols kernels found in the assembly"
+    assert not bad, bad[:5]
