@@ -119,6 +119,14 @@ mgrt_status mgrt_box_cells_host(int dim, int nx, int ny, int nz, const int face[
     mgrt_status mgrt_smooth_sweep_residual##S(const mgrt_grid *g, R *out, R *r, const R *in,       \
                                               const R *f, R omega, int iters, int zcount,          \
                                               mgrt_stream s);                                      \
+    /* The same sweep, which leaves rc = Restrict(residual of `out`) on the coarse grid behind     \
+       and never writes the fine residual: smoother_iterate, compute_residuals and restrict        \
+       (multigridsolver2D.cpp:51,62,71) in one pass over the fields.  Whole 2D analytic-box        \
+       grids with odd extents only (MGRT_E_UNSUPPORTED otherwise).  in == NULL: zeros. */          \
+    mgrt_status mgrt_smooth_sweep_residual_restrict##S(const mgrt_grid *fine,                      \
+                                                       const mgrt_grid *coarse, R *out, R *rc,     \
+                                                       const R *in, const R *f, R omega,           \
+                                                       int iters, int zcount, mgrt_stream s);      \
     /* out = S^iters(u + 4*P(e)): the results of mgrt_correct followed by mgrt_smooth_sweep, the   \
        corrected field never written.  Replaces correct_residual followed by the post-smoothing    \
        smoother_iterate (multigridsolver2D.cpp:77,92, multigridsolver3D.cpp:70,77).  Analytic-box  \

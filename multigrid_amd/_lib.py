@@ -40,7 +40,7 @@ class PlanDesc(C.Structure):
 
 
 # every symbol include/mgrt.h declares; checked by the CPU test-suite against the header
-_KERNELS = ["smooth_pass", "smooth", "smooth_sweep", "smooth_sweep_residual", "correct_smooth_sweep", "residual", "restrict", "residual_restrict", "correct", "prolong", "zero_outside",
+_KERNELS = ["smooth_pass", "smooth", "smooth_sweep", "smooth_sweep_residual", "smooth_sweep_residual_restrict", "correct_smooth_sweep", "residual", "restrict", "residual_restrict", "correct", "prolong", "zero_outside",
             "diff", "sumsq", "maxabs", "l2norm_reftree", "linfnorm_reftree", "sum_reftree"]
 _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "upload", "download",
             "stream_create", "stream_destroy", "sync", "zero", "box_cells_host",
@@ -89,6 +89,7 @@ def load():
             "smooth_sweep": [G, p, p, p, r, i, i, p],
             "smooth_sweep_residual": [G, p, p, p, p, r, i, i, p],
             "correct_smooth_sweep": [G, G, p, p, p, p, r, i, i, p],
+            "smooth_sweep_residual_restrict": [G, G, p, p, p, p, r, i, i, p],
             "residual": [G, p, p, p, i, p, i, i, p],
             "restrict": [G, G, p, p, i, i, p],
             "residual_restrict": [G, G, p, p, p, i, i, p],
@@ -185,6 +186,11 @@ def smooth_sweep(g, out, inp, f, omega, iters, zcount=None, stream=None):
 def correct_smooth_sweep(fine, coarse, out, u, e, f, omega, iters, zcount=None, stream=None):
     check(_fn("correct_smooth_sweep", f)(C.byref(fine), C.byref(coarse), _p(out), _p(u), _p(e), _p(f), omega, iters,
                                            fine.nz if zcount is None else zcount, _stream(stream)))
+
+
+def smooth_sweep_residual_restrict(fine, coarse, out, rc, inp, f, omega, iters, zcount=None, stream=None):
+    check(_fn("smooth_sweep_residual_restrict", f)(C.byref(fine), C.byref(coarse), _p(out), _p(rc), _p(inp), _p(f), omega,
+                                                     iters, fine.nz if zcount is None else zcount, _stream(stream)))
 
 
 def smooth_sweep_residual(g, out, r, inp, f, omega, iters, zcount=None, stream=None):

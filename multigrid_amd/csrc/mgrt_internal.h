@@ -75,8 +75,8 @@ inline bool correct_sweep_3d_supported(const mgrt_grid *g, size_t elem, int iter
 }
 
 // out = S^iters(in) on a 2D analytic-box grid, iters 1 or 2 (mgrt_smooth2d.hip); in may be null.
-// res (optional) receives the residual of out; e with its coarse grid cg (optional) makes the input
-// in + 4*P(e).
+// res (optional) receives the residual of out or, when cg is given without e, its restriction to
+// the coarse grid cg; e with its coarse grid cg (optional) makes the input in + 4*P(e).
 mgrt_status smooth_sweep_2d(const mgrt_grid *g, const mgrt_grid *cg, float *out, float *res, const float *in,
                             const float *e, const float *f, float omega, int iters, hipStream_t hs);
 mgrt_status smooth_sweep_2d(const mgrt_grid *g, const mgrt_grid *cg, double *out, double *res, const double *in,

@@ -72,6 +72,7 @@ template <> struct K<float> {
     static constexpr auto sweep = mgrt_smooth_sweep_f32;
     static constexpr auto sweep_res = mgrt_smooth_sweep_residual_f32;
     static constexpr auto correct_sweep = mgrt_correct_smooth_sweep_f32;
+    static constexpr auto sweep_res_restrict = mgrt_smooth_sweep_residual_restrict_f32;
     static constexpr auto residual = mgrt_residual_f32;
     static constexpr auto restrict_ = mgrt_restrict_f32;
     static constexpr auto resrestrict = mgrt_residual_restrict_f32;
@@ -83,6 +84,7 @@ template <> struct K<double> {
     static constexpr auto sweep = mgrt_smooth_sweep_f64;
     static constexpr auto sweep_res = mgrt_smooth_sweep_residual_f64;
     static constexpr auto correct_sweep = mgrt_correct_smooth_sweep_f64;
+    static constexpr auto sweep_res_restrict = mgrt_smooth_sweep_residual_restrict_f64;
     static constexpr auto residual = mgrt_residual_f64;
     static constexpr auto restrict_ = mgrt_restrict_f64;
     static constexpr auto resrestrict = mgrt_residual_restrict_f64;
@@ -127,8 +129,9 @@ bool sweepable(const mgrt_plan *p, const mgrt_grid &g) { return !p->desc.no_fuse
 
 // `a` smoothing iterations on *cur, as `nsweeps` out-of-place fused sweeps that ping-pong between
 // *cur and *alt (nsweeps between ceil(a/2) and a), or in place when nsweeps == 0.  With `res`, the
-// last sweep also leaves the residual of the result there; with `e` (on the coarse grid `cg`), the
-// first sweep starts from *cur + 4*P(e), the coarse-grid correction (both: nsweeps > 0 only).
+// last sweep also leaves the residual of the result there (restricted to the coarse grid `cg` when
+// that is given without `e`); with `e` (on the coarse grid `cg`), the first sweep starts from
+// *cur + 4*P(e), the coarse-grid correction (all of these: nsweeps > 0 only).
 template <class R>
 mgrt_status smooth_steps(mgrt_plan *p, mgrt_plan::Level &L, R *&cur, R *&alt, const R *f, R omega, int a, int nsweeps,
                          R *res = nullptr, bool cur_is_zero = false, const mgrt_grid *cg = nullptr, const R *e = nullptr)
@@ -143,7 +146,9 @@ mgrt_status smooth_steps(mgrt_plan *p, mgrt_plan::Level &L, R *&cur, R *&alt, co
         // a field known to be all zeros is not read (and was not cleared): the kernel takes NULL
         const R *in = cur_is_zero && i == 0 ? nullptr : cur;
         if (mgrt_status st = e && i == 0              ? K<R>::correct_sweep(&L.g, cg, alt, cur, e, f, omega, n, zc, s)
-                             : res && i + 1 == nsweeps ? K<R>::sweep_res(&L.g, alt, res, in, f, omega, n, zc, s)
+                             : res && i + 1 == nsweeps
+                                 ? (cg ? K<R>::sweep_res_restrict(&L.g, cg, alt, res, in, f, omega, n, zc, s)
+                                       : K<R>::sweep_res(&L.g, alt, res, in, f, omega, n, zc, s))
                                                        : K<R>::sweep(&L.g, alt, in, f, omega, n, zc, s))
             return st;
         R *t = cur;
@@ -192,9 +197,14 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
     const bool correct_in_sweep =
         n2 > 0 && a2 > 0 && v > 0 && recurses(L.g) &&
         (L.g.dim == 2 || (!p->fuse_rr && correct_sweep_3d_supported(&L.g, sizeof(R), n2 < a2 ? 2 : 1)));
-    if (a1 > 0)
-        if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a1, n1, res_in_sweep ? (R *)L.r : nullptr, u_is_zero))
+    // 2D: that sweep hands the coarse level its right-hand side directly (no fine residual array)
+    const bool restrict_in_sweep = res_in_sweep && L.g.dim == 2;
+    if (a1 > 0) {
+        R *res = restrict_in_sweep ? (R *)p->lv[l + 1].rhs : res_in_sweep ? (R *)L.r : nullptr;
+        if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a1, n1, res, u_is_zero,
+                                             restrict_in_sweep ? &p->lv[l + 1].g : nullptr))
             return st;
+    }
     if (recurses(L.g)) {
         mgrt_plan::Level &C = p->lv[l + 1];
         for (int k = 0; k < v; ++k) {
@@ -207,8 +217,9 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
                 if (!(res_in_sweep && k == 0))
                     if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, 0, L.g.ny, s))
                         return st;
-                if (mgrt_status st = K<R>::restrict_(&L.g, &C.g, (R *)C.rhs, (const R *)L.r, 0, C.g.ny, s))
-                    return st;
+                if (!(restrict_in_sweep && k == 0))
+                    if (mgrt_status st = K<R>::restrict_(&L.g, &C.g, (R *)C.rhs, (const R *)L.r, 0, C.g.ny, s))
+                        return st;
             }
             if (mgrt_status st = iterate<R>(p, l + 1, (R *)C.e, (const R *)C.rhs, omega, a1, a2, v, true)) // zero_mem(i), :59
                 return st;

@@ -44,15 +44,21 @@ __device__ __forceinline__ int per_pass(int v)
 // correction (the input of the post-smoother).
 enum Input { FIELD, ZEROS, CORRECTED };
 
-// RES: also r = residual of `out`, which takes one more halo ring (the residual of a point reads
+// RES = 1: also r = residual of `out`, which takes one more halo ring (the residual of a point reads
 // the final values of its four neighbours).
-template <class R, int ITERS, int RT, bool OMEGA1, Input IN, bool RES>
+// RES = 2: the residual stays in registers and `res` receives its full-weighting restriction on the
+// coarse grid `cg` (reduction_kernel, mg_0.cl:139-157): one more ring again, since a coarse point
+// weighs the residuals around it.  Whole grids with odd extents: the tile interiors then start on
+// even rows and columns, so every coarse point lies in exactly one of them, and a coarse point
+// injects exactly when it lies on a face.
+template <class R, int ITERS, int RT, bool OMEGA1, Input IN, int RES>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN == CORRECTED ? RT + 8 : 0)>())) void k_smooth2d_cols(
     mgrt_grid g, mgrt_grid cg, const R *__restrict__ in, R *__restrict__ out, const R *__restrict__ f,
     const R *__restrict__ e, R *__restrict__ res, R omega, int ntx, int ntiles)
 {
-    constexpr int H = 2 * ITERS + (RES ? 1 : 0), OX = 64 - 2 * H, OY = RT - 2 * H;
+    constexpr int H = 2 * ITERS + RES, OX = 64 - 2 * H, OY = RT - 2 * H;
     static_assert(OY > 0, "tile too short for its halo");
+    static_assert(RES != 2 || (H % 2 == 0 && OY % 2 == 0), "tile interiors must start on even rows");
     const int lane = threadIdx.x & 63;
     // the wave index through readfirstlane: everything derived from the tile stays in scalar registers
     const int tile = xcd_contiguous(blockIdx.x, gridDim.x) * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -175,29 +181,50 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN ==
             po += pitch;
         }
     }
-    if constexpr (RES) {
+    if constexpr (RES != 0) {
         // the residual kernel's expressions; cells that are neither inner nor Dirichlet get 0
         const int lo = max(jlo, first), hi = min(jhi, last + 1);
         const int dlo = jdlo >= first ? jdlo : -1, dhi = jdhi <= last ? jdhi : -1;
+        constexpr int JA = RES == 2 ? H - 1 : H, JB = RES == 2 ? RT - H + 1 : RT - H;
         R *pr = res + x + pitch * (long long)(y0 + H);
 #pragma unroll
-        for (int j = H; j < RT - H; ++j) {
+        for (int j = JA; j < JB; ++j) {
             const R xp = from_upper_lane(u[j]), xm = from_lower_lane(u[j]); // all lanes take part
             const bool inner = x_inner && j >= lo && j < hi;
             const bool dirichlet = (x_dirichlet && j >= first && j <= last) || (x_inner && (j == dlo || j == dhi));
             const R v = inner ? b[j] - (xp + xm + u[j + 1] + u[j - 1] - 4 * u[j]) : dirichlet ? b[j] - u[j] : (R)0;
-            if (stores && j <= last)
-                *pr = v;
-            pr += pitch;
+            if constexpr (RES == 1) {
+                if (stores && j <= last)
+                    *pr = v;
+                pr += pitch;
+            } else {
+                b[j] = v; // the right-hand side has done its part
+            }
+        }
+        if constexpr (RES == 2) {
+            const bool x_face = x == 0 || x == nx - 1;
+            const bool coarse_lane = stores && (x & 1) == 0;
+            R *pc = res + (x >> 1);
+#pragma unroll
+            for (int j = H; j < RT - H; j += 2) { // y0 + j is even: y0 + H is
+                const R am = from_lower_lane(b[j - 1]), ap = from_upper_lane(b[j - 1]);
+                const R bm = from_lower_lane(b[j + 1]), bp = from_upper_lane(b[j + 1]);
+                const R cm = from_lower_lane(b[j]), cp = from_upper_lane(b[j]);
+                // mg_0.cl:152-156 with c = the fine point under the coarse one
+                const R w = 1.0 / 16.0 * (am + ap + bm + bp) + 1.0 / 8.0 * (b[j - 1] + cp + cm + b[j + 1]) + 1.0 / 4.0 * (b[j]);
+                const bool face = x_face || j == jlo - 1 || j == jhi;
+                if (coarse_lane && j <= last)
+                    pc[cg.pitch * (long long)((y0 + j) >> 1)] = face ? b[j] : w;
+            }
         }
     }
 }
 
-template <class R, int ITERS, int RT, Input IN, bool RES>
+template <class R, int ITERS, int RT, Input IN, int RES>
 mgrt_status launch2d_cols(const mgrt_grid *g, const mgrt_grid *cg, R *out, R *res, const R *in, const R *e, const R *f,
                           R omega, hipStream_t hs)
 {
-    constexpr int H = 2 * ITERS + (RES ? 1 : 0);
+    constexpr int H = 2 * ITERS + RES;
     const int ntx = (g->nx + 64 - 2 * H - 1) / (64 - 2 * H), nty = (g->ny + RT - 2 * H - 1) / (RT - 2 * H);
     const int ntiles = ntx * nty, blocks = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 grid(blocks), block(64 * kWavesPerBlock);
@@ -221,13 +248,21 @@ int tuned_rows(const char *name, int dflt)
 #endif
 
 // Tile heights measured on V(2,2) cycles: 20 rows from 2049^2 up; below, 12 rows, or 14 with the
-// wider halo of the residual variant.
-template <class R, int ITERS, Input IN, bool RES>
+// wider halo of the residual variant; 24 and 16 with the restriction.
+template <class R, int ITERS, Input IN, int RES>
 mgrt_status sweep2d(const mgrt_grid *g, const mgrt_grid *cg, R *out, R *res, const R *in, const R *e, const R *f, R omega,
                     hipStream_t hs)
 {
     const bool large = (long long)g->nx * g->ny >= 1500LL * 1500LL;
-    if constexpr (RES) {
+    if constexpr (RES == 2) {
+        const int rt = MGRT_ROWS("MGRT_2D_ROWS_RST", large ? 24 : 16);
+#ifdef MGRT_TUNE
+        if (rt == 20) return launch2d_cols<R, ITERS, 20, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+        if (rt == 28) return launch2d_cols<R, ITERS, 28, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+#endif
+        if (rt == 16) return launch2d_cols<R, ITERS, 16, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+        return launch2d_cols<R, ITERS, 24, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+    } else if constexpr (RES == 1) {
         const int rt = MGRT_ROWS("MGRT_2D_ROWS_RES", large ? 20 : 14);
 #ifdef MGRT_TUNE
         if (rt == 16) return launch2d_cols<R, ITERS, 16, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
@@ -252,10 +287,12 @@ mgrt_status sweep2d_any(const mgrt_grid *g, const mgrt_grid *cg, R *out, R *res,
 #define MGRT_2D(IN, RES) \
     (iters == 1 ? sweep2d<R, 1, IN, RES>(g, cg, out, res, in, e, f, omega, hs) : sweep2d<R, 2, IN, RES>(g, cg, out, res, in, e, f, omega, hs))
     if (e)
-        return MGRT_2D(CORRECTED, false);
+        return MGRT_2D(CORRECTED, 0);
+    if (res && cg) // res lives on the coarse grid
+        return in ? MGRT_2D(FIELD, 2) : MGRT_2D(ZEROS, 2);
     if (res)
-        return in ? MGRT_2D(FIELD, true) : MGRT_2D(ZEROS, true);
-    return in ? MGRT_2D(FIELD, false) : MGRT_2D(ZEROS, false);
+        return in ? MGRT_2D(FIELD, 1) : MGRT_2D(ZEROS, 1);
+    return in ? MGRT_2D(FIELD, 0) : MGRT_2D(ZEROS, 0);
 #undef MGRT_2D
 }
 
@@ -263,8 +300,9 @@ mgrt_status sweep2d_any(const mgrt_grid *g, const mgrt_grid *cg, R *out, R *res,
 
 namespace mgrt {
 
-// out = S^iters(in); with res != nullptr also res = residual of out; with e != nullptr (and the
-// coarse grid cg) the input is in + 4*P(e) instead of in.  in == nullptr: a field of zeros.
+// out = S^iters(in); with res != nullptr also res = residual of out, or, when cg is given without e,
+// its restriction to the coarse grid cg; with e != nullptr (and cg) the input is in + 4*P(e) instead
+// of in.  in == nullptr: a field of zeros.
 mgrt_status smooth_sweep_2d(const mgrt_grid *g, const mgrt_grid *cg, float *out, float *res, const float *in,
                             const float *e, const float *f, float omega, int iters, hipStream_t hs)
 {

@@ -656,7 +656,48 @@ mgrt_status correct_smooth_sweep(const mgrt_grid *fine, const mgrt_grid *coarse,
     return smooth_sweep_2d(fine, coarse, out, nullptr, u, e, f, omega, iters, (hipStream_t)s);
 }
 
+// out = S^iters(in) and rc = Restrict(f - A out): the pre-smoother with everything the coarse level
+// needs from this one.
+template <class R>
+mgrt_status smooth_sweep_residual_restrict(const mgrt_grid *fine, const mgrt_grid *coarse, R *out, R *rc, const R *in,
+                                           const R *f, R omega, int iters, int zcount, mgrt_stream s)
+{
+    const char *who = "mgrt_smooth_sweep_residual_restrict";
+    if (mgrt_status st = require_init()) return st;
+    if (mgrt_status st = check_grid(fine, who)) return st;
+    if (mgrt_status st = check_grid(coarse, who)) return st;
+    MGRT_REQUIRE(out && rc && f, "%s: null field", who);
+    MGRT_REQUIRE(out != in && out != f && rc != out && rc != in && rc != f, "%s: outputs must not alias another field", who);
+    MGRT_REQUIRE(fine->dim == coarse->dim, "%s: grids of different dimension", who);
+    MGRT_REQUIRE(coarse->nx == (fine->nx + 1) / 2 && coarse->gny == (fine->gny + 1) / 2,
+                 "%s: coarse grid %dx%d is not the half of %dx%d", who, coarse->nx, coarse->gny, fine->nx, fine->gny);
+    MGRT_REQUIRE(zcount >= 0 && zcount <= fine->nz, "%s: zcount %d outside [0,%d]", who, zcount, fine->nz);
+    if (fine->cells || coarse->cells)
+        return fail(MGRT_E_UNSUPPORTED, "%s: byte cell maps are not supported", who);
+    if (iters != 1 && iters != 2)
+        return fail(MGRT_E_UNSUPPORTED, "%s: iters must be 1 or 2, got %d", who, iters);
+    if (fine->dim != 2 || fine->nx % 2 == 0 || fine->ny % 2 == 0)
+        return fail(MGRT_E_UNSUPPORTED, "%s: 2D grids with odd extents only", who);
+    if (fine->y0 != 0 || fine->ny != fine->gny || coarse->y0 != 0 || coarse->ny != coarse->gny)
+        return fail(MGRT_E_UNSUPPORTED, "%s: whole grids only, not y-slabs", who);
+    return smooth_sweep_2d(fine, coarse, out, rc, in, nullptr, f, omega, iters, (hipStream_t)s);
+}
+
 } // namespace
+
+extern "C" mgrt_status mgrt_smooth_sweep_residual_restrict_f32(const mgrt_grid *fine, const mgrt_grid *coarse, float *out,
+                                                               float *rc, const float *in, const float *f, float omega,
+                                                               int iters, int zcount, mgrt_stream s)
+{
+    return smooth_sweep_residual_restrict<float>(fine, coarse, out, rc, in, f, omega, iters, zcount, s);
+}
+
+extern "C" mgrt_status mgrt_smooth_sweep_residual_restrict_f64(const mgrt_grid *fine, const mgrt_grid *coarse, double *out,
+                                                               double *rc, const double *in, const double *f, double omega,
+                                                               int iters, int zcount, mgrt_stream s)
+{
+    return smooth_sweep_residual_restrict<double>(fine, coarse, out, rc, in, f, omega, iters, zcount, s);
+}
 
 extern "C" mgrt_status mgrt_correct_smooth_sweep_f32(const mgrt_grid *fine, const mgrt_grid *coarse, float *out,
                                                      const float *u, const float *e, const float *f, float omega,

@@ -310,6 +310,17 @@ def test_fused_sweep_2d_with_residual_and_with_correction(dev, mgo, dt, shape):
             assert torch.equal(got_r.view(torch.uint8), want_r.view(torch.uint8)), (shape, faces, iters, "res0: r")
             if shape[0] % 2 == 0 or shape[1] % 2 == 0:
                 continue  # transfers between levels need odd extents
+            # residual restricted in the sweep, against the three kernels
+            if min(shape) >= 3:
+                for inp in (du, None):
+                    L.smooth_sweep(g, want_u, inp, df, omega, iters)
+                    L.residual(g, want_r, want_u, df, True)
+                    want_c = torch.full(cs, 2.0, dtype=du.dtype, device=dev)
+                    L.restrict(g, gc, want_c, want_r)
+                    got_c = torch.full(cs, 4.0, dtype=du.dtype, device=dev)
+                    L.smooth_sweep_residual_restrict(g, gc, got_u, got_c, inp, df, omega, iters)
+                    assert torch.equal(got_u.view(torch.uint8), want_u.view(torch.uint8)), (shape, faces, iters, "rst: u")
+                    assert torch.equal(got_c.view(torch.uint8), want_c.view(torch.uint8)), (shape, faces, iters, "rst: rc")
             # corrected input, against the oracle
             ref = np.empty_like(u)
             mgo.correct(cell, ref, u, e)
