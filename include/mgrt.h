@@ -93,6 +93,10 @@ mgrt_status mgrt_zero(void *ptr, size_t bytes, mgrt_stream s); /* zero_memory, c
  * replaces genBuffer (rectangularborderhandler.cpp:46-68,89-114).  Host memory, dense layout. */
 mgrt_status mgrt_box_cells_host(int dim, int nx, int ny, int nz, const int face[6], unsigned char *cells);
 
+/* Whether mgrt_correct_smooth_sweep_f32/_f64 (below) has a kernel for this fine grid, element size
+ * (4 or 8) and iteration count: 1 or 0.  For callers that plan their launches ahead. */
+int mgrt_correct_smooth_sweep_supported(const mgrt_grid *fine, int elem_size, int iters);
+
 #define MGRT_DECLARE_KERNELS(R, S)                                                                 \
     /* One colour pass of the weighted Gauss-Seidel smoother, in place.  Replaces                 \
        iteration_kernel (mg_1.cl:91-104, mg_0.cl:86-98) as launched by smoother_iterate           \

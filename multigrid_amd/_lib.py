@@ -45,7 +45,7 @@ _KERNELS = ["smooth_pass", "smooth", "smooth_sweep", "smooth_sweep_residual", "s
 _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "upload", "download",
             "stream_create", "stream_destroy", "sync", "zero", "box_cells_host",
             "plan_create", "plan_destroy", "plan_levels", "plan_level_dims", "plan_set_cells",
-            "plan_vcycle", "plan_fmg"]
+            "plan_vcycle", "plan_fmg", "correct_smooth_sweep_supported"]
 SYMBOLS = ["mgrt_" + n for n in _RUNTIME] + ["mgrt_%s_%s" % (k, s) for k in _KERNELS for s in ("f32", "f64")]
 
 _lib = None
@@ -82,6 +82,8 @@ def load():
         f.argtypes = args
     lib.mgrt_plan_levels.restype = i
     lib.mgrt_plan_levels.argtypes = [p]
+    lib.mgrt_correct_smooth_sweep_supported.restype = i
+    lib.mgrt_correct_smooth_sweep_supported.argtypes = [G, i, i]
     for S, r in (("f32", C.c_float), ("f64", C.c_double)):
         ksig = {
             "smooth_pass": [G, p, p, r, i, i, i, i, p],
@@ -181,6 +183,12 @@ def smooth(g, u, f, omega, iters, zcount=None, stream=None):
 def smooth_sweep(g, out, inp, f, omega, iters, zcount=None, stream=None):
     check(_fn("smooth_sweep", f)(C.byref(g), _p(out), _p(inp), _p(f), omega, iters,
                                    g.nz if zcount is None else zcount, _stream(stream)))
+
+
+def correct_sweep_supported(fine, dtype, iters):
+    """Whether correct_smooth_sweep has a kernel for this fine grid, torch dtype and iteration count."""
+    import torch
+    return bool(load().mgrt_correct_smooth_sweep_supported(C.byref(fine), 4 if dtype == torch.float32 else 8, iters))
 
 
 def correct_smooth_sweep(fine, coarse, out, u, e, f, omega, iters, zcount=None, stream=None):

@@ -699,6 +699,15 @@ extern "C" mgrt_status mgrt_smooth_sweep_residual_restrict_f64(const mgrt_grid *
     return smooth_sweep_residual_restrict<double>(fine, coarse, out, rc, in, f, omega, iters, zcount, s);
 }
 
+extern "C" int mgrt_correct_smooth_sweep_supported(const mgrt_grid *fine, int elem_size, int iters)
+{
+    if (!fine || fine->cells || (iters != 1 && iters != 2) || (elem_size != 4 && elem_size != 8))
+        return 0;
+    if (fine->dim == 2)
+        return fine->nx % 2 == 1 && fine->gny % 2 == 1;
+    return correct_sweep_3d_supported(fine, (size_t)elem_size, iters);
+}
+
 extern "C" mgrt_status mgrt_correct_smooth_sweep_f32(const mgrt_grid *fine, const mgrt_grid *coarse, float *out,
                                                      const float *u, const float *e, const float *f, float omega,
                                                      int iters, int zcount, mgrt_stream s)

@@ -224,7 +224,7 @@ class SlabCycle:
         cur, alt = u, L.work
         cur, alt, halo_valid = self._smooth(L, cur, alt, f, omega, a1, halo_valid)
         last = l + 1 == self.ndist
-        for _ in range(v):
+        for it in range(v):
             if not halo_valid:
                 self._exchange(L, cur)
                 halo_valid = True
@@ -249,10 +249,23 @@ class SlabCycle:
                 if not ok:
                     self._exchange(C, res)
                 e_local, egrid = res, C.grid
-            # every local row is corrected, halo rows included: they stay valid without an exchange
-            k.correct(L.grid, egrid, cur, cur, e_local, 0, L.nyl)
+            if it + 1 == v and a2 >= 2 and self._correct_in_sweep(L):
+                # the last correction rides in the first post-smoothing sweep: same values, and the
+                # corrected field is never written (halo rows of cur and e_local are valid here)
+                k.correct_smooth_sweep(L.grid, egrid, alt, cur, e_local, f, omega, 2, self._zcount(L))
+                cur, alt = alt, cur
+                halo_valid = False
+                a2 -= 2
+            else:
+                # every local row is corrected, halo rows included: they stay valid without an exchange
+                k.correct(L.grid, egrid, cur, cur, e_local, 0, L.nyl)
         cur, alt, halo_valid = self._smooth(L, cur, alt, f, omega, a2, halo_valid)
         return cur, halo_valid
+
+    def _correct_in_sweep(self, L):
+        """Whether the kernel set has a sweep that applies the correction on this level's slab."""
+        ask = getattr(self.k, "correct_sweep_supported", None)
+        return bool(ask and ask(L.grid, self.dtype, 2))
 
     def vcycle(self, u, f, omega=1.0, a1=2, a2=2, v=1, ncycles=1, history=False):
         """ncycles x iterate(u, f, omega, a1, a2, v) in place on this rank's rows.  The halo rows

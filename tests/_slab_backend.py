@@ -67,6 +67,14 @@ class OracleKernels:
         yhi = gf.shape[1] if yhi is None else yhi
         out.numpy()[:, ylo:yhi, :] = ow[:, gf.y0 + ylo:gf.y0 + yhi, :]
 
+    def correct_sweep_supported(self, g, dtype, iters):
+        return iters == 2  # so that the CPU tests walk the driver's fused branch as well
+
+    def correct_smooth_sweep(self, gf, gc, out, u, e, f, omega, iters, zcount=None):
+        tmp = torch.empty_like(u)
+        self.correct(gf, gc, tmp, u, e)
+        self.smooth_sweep(gf, out, tmp, f, omega, iters, zcount)
+
     def sumsq(self, g, x, out, ylo=0, yhi=None):
         yhi = g.shape[1] if yhi is None else yhi
         out[0] = float((x.numpy()[:, ylo:yhi, :].astype(np.float64) ** 2).sum())

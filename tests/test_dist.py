@@ -68,6 +68,9 @@ GPU_CASES = [
     (2, (33, 65, 65), "f32", 1.0, 2, 2, 1, 2, True, 9 ** 3),
     (2, (65, 129, 33), "f64", 0.9, 3, 1, 2, 1, True, 17 ** 3),
     (3, (33, 129, 33), "f32", 1.0, 2, 2, 1, 2, False, 9 ** 3),
+    # wide planes: the slabs of level 0 take the sweep that applies the correction itself
+    (2, (9, 641, 513), "f32", 1.0, 2, 2, 1, 2, True, 5 * 321 * 257),
+    (2, (9, 641, 513), "f32", 0.9, 1, 3, 2, 1, False, 5 * 321 * 257),
 ]
 
 
