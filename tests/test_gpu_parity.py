@@ -276,7 +276,8 @@ def test_fused_sweep_2d_matches_oracle(dev, mgo, dt, shape):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
-@pytest.mark.parametrize("shape", [(5, 5), (9, 17), (33, 65), (64, 70), (130, 67), (257, 129), (300, 1601)],
+@pytest.mark.parametrize("shape", [(5, 5), (9, 17), (33, 65), (64, 70), (130, 67), (257, 129), (300, 1601), (1025, 513),
+                                   (33, 4097), (2049, 65)],
                          ids=lambda s: "x".join(map(str, s[::-1])))
 def test_fused_sweep_2d_with_residual_and_with_correction(dev, mgo, dt, shape):
     """2D: the sweep that also writes the residual against sweep + residual kernel, and the sweep whose
