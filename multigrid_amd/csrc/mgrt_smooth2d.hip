@@ -157,9 +157,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN ==
                     fixed = mine && ((x_dirichlet && j >= fst && j <= lst) || (x_inner && (j == dlo || j == dhi)));
                 }
                 const R val = 0.25 * (from_upper_lane(u[j]) + from_lower_lane(u[j]) + u[j + 1] + u[j - 1] - b[j]);
+                // for omega == 1 the double expression reduces exactly to val + 0*u evaluated in R
+                // (the product keeps the sign of a zero result and a non-finite u as the reference does)
                 R gs;
                 if constexpr (OMEGA1)
-                    gs = val;
+                    gs = val + (R)0 * u[j];
                 else
                     gs = val * omega + (1.0 - omega) * u[j];
                 u[j] = relax ? gs : fixed ? b[j] : u[j];

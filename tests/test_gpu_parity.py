@@ -411,6 +411,30 @@ def test_fused_sweep_3d_with_correction(dev, mgo, shape):
         L.correct_smooth_sweep(gsm, gcsm, torch.empty_like(z), z, torch.zeros((5, 17, 33), device=dev), z, 1.0, 2)
 
 
+@pytest.mark.parametrize("shape", [(33, 70), (9, 40, 70)], ids=["2D", "3D"])
+def test_fused_sweeps_keep_the_sign_of_zero(dev, mgo, shape):
+    """omega == 1 takes a shortened expression in the fused kernels; it must still give the zeros
+    the reference's full expression gives (val*1 + 0*u: -0 + +0 = +0, -0 + -0 = -0).  Fields of
+    signed zeros with a zero right-hand side make every update such a case."""
+    import torch
+    from multigrid_amd import _lib as L
+    rng = np.random.default_rng(5)
+    u = np.where(rng.random(shape) < 0.5, np.float32(0.0), np.float32(-0.0)).astype(np.float32)
+    f = np.zeros(shape, np.float32)
+    cell = mgo.box_cells(shape, (3,) * 6)  # Neumann faces: nothing is overwritten by f
+    g = L.grid(shape, faces=(3,) * 6)
+    for iters in (1, 2):
+        ref = u.copy()
+        for _ in range(iters):
+            for odd in (0, 1):
+                mgo.smooth_pass(cell, ref, f, np.float32(1.0), odd)
+        out = torch.full(shape, 3.0, device=dev)
+        L.smooth_sweep(g, out, to_dev(u, dev), to_dev(f, dev), 1.0, iters)
+        got = out.cpu().numpy()
+        assert np.signbit(ref).any() and not np.signbit(ref).all()
+        assert bits_equal(got, ref), (shape, iters, int((np.signbit(got) != np.signbit(ref)).sum()))
+
+
 def test_fused_sweep_on_a_slab(dev):
     """Rows of a y-slab (odd global offset, so the colours are shifted) equal the whole-grid rows
     wherever the halo of 2*iters rows was available."""
