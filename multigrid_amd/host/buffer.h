@@ -54,7 +54,7 @@ public:
     }
     BidimArray<real> read(mgrt::Stream &q) const
     {
-        BidimArray<real> a(m_w, m_h);
+        BidimArray<real> a(m_w, m_h, mgrt::detail::Uninitialized());
         download(a.data(), q);
         return a;
     }
@@ -81,7 +81,7 @@ public:
     }
     TridimArray<real> read(mgrt::Stream &q) const
     {
-        TridimArray<real> a(m_w, m_h, m_d);
+        TridimArray<real> a(m_w, m_h, m_d, mgrt::detail::Uninitialized());
         download(a.data(), q);
         return a;
     }
