@@ -109,12 +109,12 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
     __syncthreads();
 
     // `iters` smoothing iterations on level l, in place (smoother_iterate, multigridsolver3D.cpp:111-132)
+    const bool omega_is_one = omega == (R)1;
     auto smooth = [&](int l, int iters) {
         const Lvl L = level(l);
         R *u = u_of(l);
         const R *f = u + L.n;
         const int hx = (L.nx + 1) / 2;
-        const int zload = L.zcount < L.nz ? L.zcount + 1 : L.nz;
         for (int it = 0; it < 2 * iters; ++it) {
             const int odd = it & 1;
             for (int idx = tid; idx < hx * L.ny; idx += kThreads) {
@@ -135,48 +135,47 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
                 // class of the column where it does not depend on z, else -1
                 const int lat = y == 0 ? face[2] : y == L.ny - 1 ? face[3] : x == 0 ? face[0] : x == L.nx - 1 ? face[1] : -1;
                 const int col = x + L.p * y;
-                // the in-plane neighbours have the other colour and do not change during this
-                // pass: plane z+1 is fetched while plane z is computed
-                const bool gather = lat < 0; // only inner points read neighbours
-                struct Plane {
-                    R xp, xm, yp, ym, f, own;
+                // The in-plane neighbours have the other colour and do not change during this pass,
+                // and the column's own planes above z are still old: everything a step needs except
+                // the value just computed below it is fetched one step ahead, so that the z
+                // recurrence carries only add, subtract, the 1/6 product and the relaxation.
+                // Columns on a lateral face never relax; their neighbour offsets collapse onto the
+                // column itself so that no address outside the array is formed.
+                const bool gather = lat < 0;
+                const int oxp = gather ? 1 : 0, oxm = gather ? -1 : 0, oyp = gather ? L.p : 0, oym = gather ? -L.p : 0;
+                const int ztop = L.nz - 1;
+                struct Ahead { // raw values of the next step; summed only after this step's chain
+                    R xp, xm, yp, ym, above, f;
                 };
-                // raw values only: summing here would wait for the loads one step early
-                auto fetch = [&](int z) {
-                    const int b = col + L.s * z;
-                    Plane v;
-                    v.own = u[b];
-                    v.f = f[b];
-                    v.xp = v.xm = v.yp = v.ym = 0;
-                    if (gather) {
-                        v.xp = u[b + 1];
-                        v.xm = u[b - 1];
-                        v.yp = u[b + L.p];
-                        v.ym = u[b - L.p];
-                    }
-                    return v;
+                auto fetch = [&](int z) { // plane z of the neighbours and of f, plane z + 1 of the column
+                    const int b = col + L.s * (z < ztop ? z : ztop);
+                    Ahead a;
+                    a.xp = u[b + oxp], a.xm = u[b + oxm], a.yp = u[b + oyp], a.ym = u[b + oym];
+                    a.above = u[col + L.s * (z + 1 < ztop ? z + 1 : ztop)];
+                    a.f = f[b];
+                    return a;
                 };
-                Plane cur = {0, 0, 0, 0, 0, 0};
+                const Ahead first = fetch(0);
+                R sum4 = first.xp + first.xm + first.yp + first.ym; // mg_1.cl:35-42: the first three additions
+                R own = u[col], above = first.above, fz = first.f;
                 R below = 0;
-                if (L.zcount > 0)
-                    cur = fetch(0);
                 for (int z = 0; z < L.zcount; ++z) {
-                    Plane nxt = {0, 0, 0, 0, 0, 0};
-                    if (z + 1 < zload)
-                        nxt = fetch(z + 1);
-                    const int t = lat >= 0 ? lat : (z == 0 ? face[4] : z == L.nz - 1 ? face[5] : MGRT_CELL_INNER);
-                    R next = cur.own;
-                    if (t == MGRT_CELL_INNER) {
-                        const R above = z + 1 < zload ? nxt.own : (R)0;
-                        const R val = (1.0 / 6.0) * (cur.xp + cur.xm + cur.yp + cur.ym + above + below - cur.f);
-                        next = val * omega + (1.0 - omega) * cur.own;
-                        u[col + L.s * z] = next;
-                    } else if (t == MGRT_CELL_DIRICHLET) {
-                        next = cur.f;
-                        u[col + L.s * z] = next;
-                    }
+                    const Ahead nx = fetch(z + 1);
+                    const int t = lat >= 0 ? lat : (z == 0 ? face[4] : z == ztop ? face[5] : (int)MGRT_CELL_INNER);
+                    const R val = (1.0 / 6.0) * (sum4 + above + below - fz);
+                    R gs;
+                    if (omega_is_one)
+                        gs = val + (R)0 * own; // what the full expression reduces to, exactly
+                    else
+                        gs = val * omega + (1.0 - omega) * own;
+                    const R next = t == MGRT_CELL_INNER ? gs : (t == MGRT_CELL_DIRICHLET ? fz : own);
+                    u[col + L.s * z] = next; // frozen cells get their own value back
                     below = next;
-                    cur = nxt;
+                    // nothing of the next step is touched before this point: its loads have the
+                    // whole chain above to land
+                    __builtin_amdgcn_sched_barrier(0);
+                    sum4 = nx.xp + nx.xm + nx.yp + nx.ym;
+                    own = above, above = nx.above, fz = nx.f;
                 }
             }
             __syncthreads();
