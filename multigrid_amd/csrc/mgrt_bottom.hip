@@ -115,6 +115,46 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
         R *u = u_of(l);
         const R *f = u + L.n;
         const int hx = (L.nx + 1) / 2;
+        if (DIM == 3 && iters > 0 && 2 * iters * hx * L.ny <= kThreads) {
+            // All colour passes at once, each one plane behind the pass before it: a thread owns one
+            // column of one pass, and in time step t pass number p works on plane t - p.  The 3D
+            // colouring ignores z, so a pass at plane z needs the pass before it only up to plane
+            // z (done a step earlier) and must not yet see the pass after it there (which comes a
+            // step later): one barrier per step, and zcount + passes - 1 steps instead of
+            // passes * zcount.  Every point is computed by the same expression from the same values
+            // as in the pass-by-pass schedule below.
+            const int ncol = hx * L.ny, npass = 2 * iters;
+            const int p = tid / ncol, idx = tid - p * ncol;
+            const int y = idx / hx, x = 2 * (idx % hx) + ((p + y) & 1);
+            const bool active = p < npass && x < L.nx;
+            const int lat = !active ? (int)MGRT_CELL_OUTER
+                                    : y == 0 ? face[2] : y == L.ny - 1 ? face[3] : x == 0 ? face[0] : x == L.nx - 1 ? face[1] : -1;
+            const int col = active ? x + L.p * y : 0;
+            const bool gather = lat < 0;
+            const int oxp = gather ? 1 : 0, oxm = gather ? -1 : 0, oyp = gather ? L.p : 0, oym = gather ? -L.p : 0;
+            const int ztop = L.nz - 1;
+            R below = 0;
+            for (int t = 0; t < L.zcount + npass - 1; ++t) {
+                const int z = t - p;
+                if (active && z >= 0 && z < L.zcount) {
+                    const int b = col + L.s * z;
+                    const R xp = u[b + oxp], xm = u[b + oxm], yp = u[b + oyp], ym = u[b + oym];
+                    const R above = u[col + L.s * (z < ztop ? z + 1 : ztop)], own = u[b], fz = f[b];
+                    const int cls = lat >= 0 ? lat : (z == 0 ? face[4] : z == ztop ? face[5] : (int)MGRT_CELL_INNER);
+                    const R val = (1.0 / 6.0) * (xp + xm + yp + ym + above + below - fz);
+                    R gs;
+                    if (omega_is_one)
+                        gs = val + (R)0 * own; // what the full expression reduces to, exactly
+                    else
+                        gs = val * omega + (1.0 - omega) * own;
+                    const R next = cls == MGRT_CELL_INNER ? gs : (cls == MGRT_CELL_DIRICHLET ? fz : own);
+                    u[b] = next;
+                    below = next;
+                }
+                __syncthreads();
+            }
+            return;
+        }
         for (int it = 0; it < 2 * iters; ++it) {
             const int odd = it & 1;
             for (int idx = tid; idx < hx * L.ny; idx += kThreads) {
