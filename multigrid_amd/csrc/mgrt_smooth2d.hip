@@ -27,7 +27,7 @@ constexpr int kWavesPerBlock = 4;
 // waves per SIMD the register file admits with `values` field values per lane and some room to work in
 template <class R, int values> constexpr int cols_waves()
 {
-    constexpr int need = values * (int)(sizeof(R) / 4) + 40, w = 512 / need;
+    constexpr int need = values * (int)(sizeof(R) / 4) + 48, w = 512 / need;
     return w < 1 ? 1 : w > 8 ? 8 : w;
 }
 
@@ -52,7 +52,7 @@ enum Input { FIELD, ZEROS, CORRECTED };
 // even rows and columns, so every coarse point lies in exactly one of them, and a coarse point
 // injects exactly when it lies on a face.
 template <class R, int ITERS, int RT, bool OMEGA1, Input IN, int RES>
-__global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN == CORRECTED ? RT + 8 : 0)>())) void k_smooth2d_cols(
+__global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN == CORRECTED ? RT + 8 : 0) + (RES == 2 ? 12 : 0)>())) void k_smooth2d_cols(
     mgrt_grid g, mgrt_grid cg, const R *__restrict__ in, R *__restrict__ out, const R *__restrict__ f,
     const R *__restrict__ e, R *__restrict__ res, R omega, int ntx, int ntiles)
 {
