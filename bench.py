@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
-"""Headline benchmark: 3D 513^3 Poisson, Dirichlet box, float, V(2,2) multigrid cycles on MI355X.
+"""Benchmark of the V-cycle engine on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME]
 
-A step is one V(2,2) cycle (omega = 1, pre/post smoothing 2+2, one coarse solve per level, smoother
-over every z plane) on fields already resident in HBM.  Prints ONE JSON line:
+A step is one V(2,2) cycle (omega = 1, pre/post smoothing 2+2, one coarse solve per level, 3D
+smoother over every z plane) on fields already resident in HBM.  Prints ONE JSON line:
 value = finest-grid points x cycles / second over all GPUs.
 
-For N > 1 the driver launches one process per GPU with torch.distributed.run; the 513^3 grid is cut
-into N slabs along y (multigrid_amd/dist.py): halo exchange over RCCL before each fused sweep, the
-levels of at most 129^3 points solved whole on every rank.  Total work is fixed: strong scaling.
+--config picks the workload (default 3d513, the headline: 3D 513^3 Poisson, Dirichlet box, float):
+2d257, 2d4097mixed, 3d257neumann, 3d513, 3d513f64, 3d1025f64.  Every line carries the roofline
+of that workload's dominant kernel and the CPU oracle timed on the same extents.
+
+For N > 1 there is one process per GPU (3d513 only): started by the caller with torch.distributed.run,
+or, when WORLD_SIZE is not set, started here as child processes before anything touches a GPU.  The
+grid is cut into N slabs along y (multigrid_amd/dist.py); total work is fixed: strong scaling.  On a
+box with fewer than N GPUs the ranks share the devices over gloo (a rehearsal of the path, marked as
+such in the output, not a measurement).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,24 +29,53 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
+D_, N_ = 2, 3  # MGRT_CELL_DIRICHLET, MGRT_CELL_NEUMANN
+CONFIGS = {
+    # name: (shape (nz, ny, nx) or (ny, nx), dtype, faces x-lo x-hi y-lo y-hi z-lo z-hi, oracle problem, workload)
+    "2d257": ((257, 257), "f32", (D_,) * 6, 1, "2D Poisson 257^2 Dirichlet box"),
+    "2d4097mixed": ((4097, 4097), "f32", (D_, D_, N_, N_, D_, D_), 1,
+                    "2D Poisson 4097^2, Dirichlet x faces, Neumann (frozen, as in the reference) y faces"),
+    "3d257neumann": ((257,) * 3, "f32", (N_,) * 6, 0, "3D Poisson 257^3, all faces Neumann (frozen, as in the reference)"),
+    "3d513": ((513,) * 3, "f32", (D_,) * 6, 0, "3D Poisson 513^3 Dirichlet box"),
+    "3d513f64": ((513,) * 3, "f64", (D_,) * 6, 0, "3D Poisson 513^3 Dirichlet box"),
+    "3d1025f64": ((1025,) * 3, "f64", (D_,) * 6, 0, "3D Poisson 1025^3 Dirichlet box"),
+}
 
-def make_problem(n, device):
-    """tridimF1/tridimS1 of the reference (programstate.cpp:114-122) sampled as discretize_func does
-    (functionhandler.cpp:64-84): interior F*h*h in float, Dirichlet faces the exact solution."""
+
+def make_problem(shape, dtype, faces, device):
+    """The reference's test problems sampled as discretize_func does (functionhandler.cpp:25-45,64-84):
+    3D tridimF1/tridimS1 (programstate.cpp:114-122), 2D sinfunc2/sinfunc2sol (:84-94).  Interior
+    F*h*h in `real`, Dirichlet cells the exact solution, Neumann cells the solution times h."""
     import math
     import torch
-    c = (torch.arange(n, device=device, dtype=torch.float32) / (n - 1)).double()
-    s = torch.sin(math.pi * c)
-    sol = (s[:, None, None] * s[None, :, None] * s[None, None, :])
-    dh = torch.tensor(1.0 / (n - 1), dtype=torch.float32, device=device)
-    f = ((-3.0 * math.pi * math.pi) * sol).float() * dh * dh
-    sol = sol.float()
-    f[0], f[-1], f[:, 0], f[:, -1], f[:, :, 0], f[:, :, -1] = sol[0], sol[-1], sol[:, 0], sol[:, -1], sol[:, :, 0], sol[:, :, -1]
-    return f.contiguous(), sol.contiguous()
+    ax = [(torch.arange(n, device=device, dtype=dtype) / (n - 1)).double() for n in shape]
+    if len(shape) == 3:
+        s = [torch.sin(math.pi * a) for a in ax]
+        sol = s[0][:, None, None] * s[1][None, :, None] * s[2][None, None, :]
+        rhs = (-3.0 * math.pi * math.pi) * sol
+    else:
+        y, x = ax[0][:, None], ax[1][None, :]
+        sol = torch.sin(26 * math.pi * x) + torch.cos(50 * math.pi * y) + torch.sin(math.pi * x)
+        rhs = -26 * 26 * math.pi ** 2 * torch.sin(26 * math.pi * x) - 50 * 50 * math.pi ** 2 * torch.cos(50 * math.pi * y) \
+            - math.pi ** 2 * torch.sin(math.pi * x)
+        rhs = rhs.expand(shape)
+    dh = torch.tensor(1.0 / (shape[-1] - 1), dtype=dtype, device=device)
+    f = rhs.to(dtype) * dh * dh
+    sol = sol.to(dtype)
+    # faces in the reference's fill order (rectangularborderhandler.cpp:59-62,103-108): later ones win
+    nd = len(shape)
+    order = [(nd - 3, 4), (nd - 3, 5), (nd - 1, 0), (nd - 1, 1), (nd - 2, 2), (nd - 2, 3)] if nd == 3 else \
+        [(0, 2), (0, 3), (1, 0), (1, 1)]
+    for axis, face in order:
+        idx = [slice(None)] * nd
+        idx[axis] = 0 if face % 2 == 0 else -1
+        idx = tuple(idx)
+        f[idx] = sol[idx] if faces[face] == D_ else sol[idx] * dh
+    return f.contiguous()
 
 
-def pmc_traffic(kernel, n, fields):
-    """HBM bytes per launch of `kernel` at n^3 from the committed counter passes (profiles/
+def pmc_traffic(kernel, n, dtype, fields):
+    """HBM bytes per launch of `kernel` at extent n from the committed counter passes (profiles/
     pmc_traffic.json, written by tools/pmc_traffic.py from separate FETCH_SIZE and WRITE_SIZE
     rocprofv3 runs).  `fields` maps positions in the kernel's template argument list to the values
     that pick the variant timed here.  None when no pass for this size is on file: counters cannot
@@ -48,7 +84,7 @@ def pmc_traffic(kernel, n, fields):
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             for row in json.load(fh):
                 args = [a.strip() for a in row["template"].split(",")]
-                if row["kernel"] == kernel and row["n"] == n and row["dtype"] == "f32" and \
+                if row["kernel"] == kernel and row["n"] == n and row["dtype"] == dtype and \
                         all(i < len(args) and args[i] == v for i, v in fields.items()):
                     return row["traffic_bytes"]
     except (OSError, ValueError, KeyError):
@@ -56,9 +92,20 @@ def pmc_traffic(kernel, n, fields):
     return None
 
 
-def cpu_baseline(n_sample):
-    """The oracle's C restatement (oracle/libmg_oracle.so, OpenMP) timed on this host on a bounded
-    sample: one V(2,2) cycle of the same problem at n_sample^3."""
+def cpu_threads():
+    """Threads for the CPU leg: what the host grants this job.  OMP_NUM_THREADS, where the box sets it,
+    is this job's share of a machine whose affinity mask shows every core; otherwise the mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        n = min(n, int(os.environ["OMP_NUM_THREADS"]))
+    except (KeyError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(name, budget_s=12.0):
+    """The oracle's C restatement (oracle/libmg_oracle.so, OpenMP) timed on this host on the same
+    extents, dtype and problem: V(2,2) cycles from a zero guess for about `budget_s` seconds."""
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -66,22 +113,44 @@ def cpu_baseline(n_sample):
     o = _oracle.load("mgo")
     if o is None:
         return None
-    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    shape, dt, faces, problem, _ = CONFIGS[name]
+    npdt = np.float32 if dt == "f32" else np.float64
+    threads = cpu_threads()
     o.set_num_threads(threads)
-    shape = (n_sample,) * 3
-    f, _ = o.discretize(0, shape, np.float32)
-    u = np.zeros(shape, np.float32)
-    o.mg(u, f, np.float32(1.0), 2, 2, 1, 1, True)  # warm: page in, spin threads up
+    if faces != (D_,) * 6:
+        # frozen faces: a callback per point would dominate, and their cells are never touched, so the
+        # box rule with a right-hand side of the same shape costs the CPU the same work per point
+        note = " (all-Dirichlet box map: Neumann cells are no-ops in the reference, the work per point is the same)"
+    else:
+        note = ""
+    f, _ = o.discretize(problem, shape, npdt)
+    u = np.zeros(shape, npdt)
+    t0 = time.perf_counter()
+    o.mg(u, f, npdt(1.0), 2, 2, 1, 1, True)  # warm: page in, spin threads up
+    first = time.perf_counter() - t0
     reps, t0 = 0, time.perf_counter()
-    while reps < 3 or time.perf_counter() - t0 < 10.0:
-        o.mg(u, f, np.float32(1.0), 2, 2, 1, 1, True)
+    while reps < 1 or (time.perf_counter() - t0 + first < budget_s and reps < 1000):
+        o.mg(u, f, npdt(1.0), 2, 2, 1, 1, True)
         reps += 1
-        if time.perf_counter() - t0 > 30.0:
-            break
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": n_sample ** 3 / dt, "unit": "DOF/s", "cores": threads, "kind": "port",
-            "sample": "%d V(2,2) cycles of the same problem at %d^3 (float, full-z), %.3f s each"
-                      % (reps, n_sample, dt)}
+    dt_s = (time.perf_counter() - t0) / reps
+    dof = float(np.prod(shape))
+    return {"value": dof / dt_s, "unit": "DOF/s", "cores": threads, "kind": "port",
+            "sample": "%d V(2,2) cycles of the same problem at %s (%s, full-z), %.3f s each%s"
+                      % (reps, "x".join(map(str, shape)), dt, dt_s, note)}
+
+
+def spawn_ranks(args, argv):
+    """python bench.py --gpus N with no launcher around it: start N ranks as children (nothing in this
+    process has touched a GPU), pass their output through and leave with their exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -89,16 +158,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=513, help="finest extent per axis (2^k+1)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="3d513")
+    ap.add_argument("--n", type=int, default=None, help="override the finest extent per axis (2^k+1)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-n", type=int, default=257)
     ap.add_argument("--rehearse", action="store_true",
-                    help="N > 1 on a one-GPU box: every rank on cuda:0, gloo with host staging; checks that the "
-                         "path runs, the number is not a measurement")
+                    help="N > 1 with fewer than N GPUs: ranks share the devices, gloo with host staging; checks that "
+                         "the path runs, the number is not a measurement (chosen by itself when GPUs are short)")
     ap.add_argument("--crossover", type=int, default=129 ** 3,
                     help="N > 1: levels with at most this many points are solved whole on every rank")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -107,21 +178,33 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    if args.rehearse:
-        local = 0
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    ndev = torch.cuda.device_count()  # counting devices does not initialise one
+    if ndev < 1:
+        sys.exit("bench.py: no GPU visible")
+    rehearse = args.rehearse or (world > 1 and ndev < world)
+    if rehearse:
+        local = local % ndev
+    if world > 1 and args.config != "3d513":
+        sys.exit("bench.py: the multi-GPU path runs the 3d513 workload")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        if args.rehearse:
+        if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
     _lib.init(local)
 
-    n = args.n
-    shape = (n, n, n)
-    f, _ = make_problem(n, dev)
+    shape, dtname, faces, _, workload = CONFIGS[args.config]
+    if args.n:
+        shape = (args.n,) * len(shape)
+        workload = workload.replace("%d^%d" % (CONFIGS[args.config][0][0], len(shape)), "%d^%d" % (args.n, len(shape)))
+    tdt = torch.float32 if dtname == "f32" else torch.float64
+    w = 4 if dtname == "f32" else 8
+    n = shape[-1]
+    f = make_problem(shape, tdt, faces, dev)
     u = torch.zeros_like(f)
     stream = torch.cuda.Stream()
     sync = torch.zeros(1, device=dev)
@@ -130,13 +213,13 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.all_reduce(sync.cpu() if args.rehearse else sync)
+            dist.all_reduce(sync.cpu() if rehearse else sync)
             torch.cuda.synchronize()
 
-    t_sweep = None
+    layout = None
     if world > 1:
         from multigrid_amd import dist as slab
-        cyc = slab.SlabCycle(shape, torch.float32, device=dev, zfull=True, crossover=args.crossover,
+        cyc = slab.SlabCycle(shape, tdt, device=dev, zfull=True, crossover=args.crossover,
                              use_graph=not args.no_graph)
         fl, ul = cyc.scatter(f), cyc.scatter(u)
         del f, u
@@ -148,13 +231,16 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         r1 = cyc.residual_norm(ul, fl)
-        layout = {"slab_rows": [b - a for a, b in zip(cyc.bounds, cyc.bounds[1:])], "halo_rows": slab.HALO,
-                  "distributed_levels": cyc.ndist, "replicated_from": "x".join(map(str, cyc.coarse_shape))}
+        layout = cyc.describe()
         cyc.close()
+        del fl, ul
+        f = make_problem(shape, tdt, faces, dev)
+        u = torch.zeros_like(f)
+        torch.cuda.synchronize()
 
     with torch.cuda.stream(stream):
         if world == 1:
-            plan = _lib.Plan(shape, torch.float32, zfull=True, use_graph=not args.no_graph)
+            plan = _lib.Plan(shape, tdt, faces=faces, zfull=True, use_graph=not args.no_graph)
             r0 = plan.vcycle(u, f, ncycles=0, history=True)[0]
             plan.vcycle(u, f, 1.0, 2, 2, 1, args.warmup)
             barrier()
@@ -164,67 +250,87 @@ def main():
             dt = time.perf_counter() - t0
             r1 = plan.vcycle(u, f, ncycles=0, history=True)[0]
             plan.close()
-            layout = None
-        else:
-            f, _ = make_problem(n, dev)
-            u = torch.zeros_like(f)
 
-        # dominant kernel: the pre-smoothing sweep of the finest level, which performs two red-black
-        # iterations and leaves the residual behind (the longest launch of the cycle), timed alone
-        # with events on the stream it runs on
-        g = _lib.grid(shape)
-        reps = 20
-        work, resid = torch.empty_like(u), torch.empty_like(u)
-        _lib.smooth_sweep_residual(g, work, resid, u, f, 1.0, 2)
+        # The dominant kernel of the workload: the pre-smoothing launch of the finest level, the longest
+        # of the cycle, timed alone with events on the stream it runs on.
+        g = _lib.grid(shape, faces=faces)
+        dof = 1.0
+        for s in shape:
+            dof *= s
+        work = torch.empty_like(u)
+        if len(shape) == 2:
+            cshape = tuple((s + 1) // 2 for s in shape)
+            gc = _lib.grid(cshape, faces=faces)
+            rc = torch.empty(cshape, dtype=tdt, device=dev)
+            launch = lambda a, b: _lib.smooth_sweep_residual_restrict(g, gc, a, rc, b, f, 1.0, 2)
+            alg_bytes = (3.0 * dof + float(rc.numel())) * w
+            kernel = ("k_smooth2d_cols", "2D sweep of 2 red-black iterations that also writes the restricted residual")
+            fields = {0: "float" if w == 4 else "double", 1: "2", 5: "2"}
+        elif w == 4 and shape[1] * shape[2] > 300 * 300:
+            resid = torch.empty_like(u)
+            launch = lambda a, b: _lib.smooth_sweep_residual(g, a, resid, b, f, 1.0, 2)
+            alg_bytes = 4.0 * dof * w  # read u, read f, write the smoothed field, write the residual
+            kernel = ("k_smooth3d_fused", "3D sweep of 2 red-black iterations with the residual pass")
+            fields = {0: "float", 1: "2", 5: "true", 6: "true", 7: "false"}
+        else:
+            launch = lambda a, b: _lib.smooth_sweep(g, a, b, f, 1.0, 2)
+            alg_bytes = 3.0 * dof * w  # read u, read f, write the smoothed field
+            kernel = ("k_smooth3d_fused", "3D sweep of 2 red-black iterations")
+            fields = {0: "float" if w == 4 else "double", 1: "2", 5: "true", 6: "false", 7: "false"}
+        reps = 20 if dof < 6e8 else 6
+        launch(work, u)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for i in range(reps // 2):
-            _lib.smooth_sweep_residual(g, work, resid, u, f, 1.0, 2)
-            _lib.smooth_sweep_residual(g, u, resid, work, f, 1.0, 2)
+            launch(work, u)
+            launch(u, work)
         e1.record(stream)
         e1.synchronize()
-        t_sweep = e0.elapsed_time(e1) * 1e-3 / reps
+        t_kernel = e0.elapsed_time(e1) * 1e-3 / reps
 
     if world > 1:
-        t = torch.tensor([dt], device="cpu" if args.rehearse else dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
     if rank == 0:
-        dof = float(n) ** 3
-        alg_bytes = 4.0 * dof * 4  # read u, read f, write the smoothed field, write the residual, once each
-        achieved = alg_bytes / t_sweep / 1e9
-        # <R, ITERS, SR, NW, PD, OMEGA1, RES, COR>: two iterations, omega == 1, with the residual pass
-        traffic = pmc_traffic("k_smooth3d_fused", n, {0: "float", 1: "2", 5: "true", 6: "true", 7: "false"})
+        achieved = alg_bytes / t_kernel / 1e9
+        traffic = pmc_traffic(kernel[0], n, dtname, fields)
         # algorithmic bytes of a whole unfused V(2,2) cycle: 22 N w + 3 Nc w per level, 16 N w coarsest
-        sizes, m = [], n
+        sizes, m = [], list(shape)
         while True:
-            sizes.append(m)
-            if m <= 3:
+            pts = 1
+            for s in m:
+                pts *= s
+            sizes.append(pts)
+            if min(m) <= 3:
                 break
-            m = (m + 1) // 2
-        cyc_bytes = sum((22 * s ** 3 + 3 * ((s + 1) // 2) ** 3) * 4 for s in sizes[:-1]) + 16 * sizes[-1] ** 3 * 4
+            m = [(s + 1) // 2 for s in m]
+        cyc_bytes = sum((22 * a + 3 * b) * w for a, b in zip(sizes, sizes[1:])) + 16 * sizes[-1] * w
+        dims = "%dD %d^%d" % (len(shape), n, len(shape))
         out = {
-            "metric": "3D 513^3 V-cycle DOF/s", "value": dof * args.steps / dt, "unit": "DOF/s",
+            "metric": "%s V-cycle DOF/s" % dims, "value": dof * args.steps / dt, "unit": "DOF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            **({"rehearsal": "all ranks on one GPU over gloo: not a measurement"} if args.rehearse else {}),
-            "config": {"workload": "3D Poisson %d^3 Dirichlet box, V(2,2), omega=1, smoother over all z planes" % n,
-                       "levels": len(sizes), "graph": not args.no_graph,
+            "vs_baseline": None, "dtype": dtname, "data": "synthetic",
+            **({"rehearsal": "%d ranks on %d GPU(s) over gloo: not a measurement" % (world, ndev)} if rehearse else {}),
+            "config": {"workload": "%s, V(2,2), omega=1%s" % (workload, ", smoother over all z planes" if len(shape) == 3 else ""),
+                       "name": args.config, "levels": len(sizes), "graph": not args.no_graph,
                        "parallelism": "single GPU" if world == 1 else "%d y-slabs, RCCL halo exchange" % world,
                        "layout": layout,
                        "residual_before": r0, "residual_after_warmup_and_steps": r1},
             "vcycles_per_s": args.steps / dt,
             "cycle_gbs_unfused_model": cyc_bytes * args.steps / dt / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "k_smooth3d_fused with the residual pass, 2 red-black iterations per sweep, finest level",
+            "roofline": {"bound": "hbm", "kernel": "%s: %s, finest level" % kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_s": t_sweep},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_s": t_kernel},
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n)
-        print(json.dumps(out))
+            del f, u, work
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(args.config if not args.n else args.config)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

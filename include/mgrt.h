@@ -76,7 +76,7 @@ typedef struct mgrt_grid {
 
 /* ---- runtime: replaces CLContextLoader (clcontextloader.cpp:29-80) and cl::Buffer / queue use
  * in buffer.h:39-45,61-79 and multigridsolver3D.h:68 ------------------------------------------ */
-mgrt_status mgrt_init(int device);                  /* select device, allocate reduction scratch */
+mgrt_status mgrt_init(int device);                  /* select the device of this process */
 mgrt_status mgrt_shutdown(void);
 const char *mgrt_last_error(void);
 mgrt_status mgrt_device_name(char *buf, int len);   /* clcontextloader.cpp:59 prints the device */
@@ -151,13 +151,6 @@ int mgrt_correct_smooth_sweep_supported(const mgrt_grid *fine, int elem_size, in
        reduction_kernel (mg_1.cl:146-190, mg_0.cl:139-157).  Coarse rows cylo <= j < cyhi. */     \
     mgrt_status mgrt_restrict##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc,            \
                                  const R *rf, int cylo, int cyhi, mgrt_stream s);                  \
-    /* rc = Restrict(f - A u) in one pass that never writes the fine residual: the results of       \
-       mgrt_residual (with zero_unwritten) followed by mgrt_restrict.  Replaces the kernel pair     \
-       launched by MultigridSolver3D::iterate (multigridsolver3D.cpp:61-64).  3D grids with odd     \
-       extents only (MGRT_E_UNSUPPORTED otherwise). */                                              \
-    mgrt_status mgrt_residual_restrict##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc,   \
-                                          const R *u, const R *f, int cylo, int cyhi,              \
-                                          mgrt_stream s);                                          \
     /* out = u + 4*P(e), P bi/trilinear, injection on border cells; out may alias u.  Replaces    \
        residual_correct_kernel (mg_1.cl:200-233, mg_0.cl:167-194). */                             \
     mgrt_status mgrt_correct##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *out,            \
@@ -208,6 +201,8 @@ typedef struct mgrt_plan_desc {
     int use_graph;    /* replay each distinct cycle from a captured hipGraph (ignored on the
                          default stream, which cannot be captured) */
     int no_fuse;      /* 1: smooth with one launch per colour pass (the unfused schedule) */
+    int no_bottom;    /* 1: one launch per kernel on the coarsest levels too, instead of running them
+                         as a single launch with every level held in LDS */
 } mgrt_plan_desc;
 
 mgrt_status mgrt_plan_create(mgrt_plan **plan, const mgrt_plan_desc *desc, mgrt_stream s);

@@ -35,12 +35,12 @@ class PlanDesc(C.Structure):
     _fields_ = [
         ("dim", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
         ("elem_size", C.c_int), ("face", C.c_int * 6), ("zfull", C.c_int), ("use_graph", C.c_int),
-        ("no_fuse", C.c_int),
+        ("no_fuse", C.c_int), ("no_bottom", C.c_int),
     ]
 
 
 # every symbol include/mgrt.h declares; checked by the CPU test-suite against the header
-_KERNELS = ["smooth_pass", "smooth", "smooth_sweep", "smooth_sweep_residual", "smooth_sweep_residual_restrict", "correct_smooth_sweep", "residual", "restrict", "residual_restrict", "correct", "prolong", "zero_outside",
+_KERNELS = ["smooth_pass", "smooth", "smooth_sweep", "smooth_sweep_residual", "smooth_sweep_residual_restrict", "correct_smooth_sweep", "residual", "restrict", "correct", "prolong", "zero_outside",
             "diff", "sumsq", "maxabs", "l2norm_reftree", "linfnorm_reftree", "sum_reftree"]
 _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "upload", "download",
             "stream_create", "stream_destroy", "sync", "zero", "box_cells_host",
@@ -94,7 +94,6 @@ def load():
             "smooth_sweep_residual_restrict": [G, G, p, p, p, p, r, i, i, p],
             "residual": [G, p, p, p, i, p, i, i, p],
             "restrict": [G, G, p, p, i, i, p],
-            "residual_restrict": [G, G, p, p, p, i, i, p],
             "correct": [G, G, p, p, p, i, i, p],
             "prolong": [G, G, p, p, i, i, p],
             "zero_outside": [G, p, p],
@@ -216,11 +215,6 @@ def restrict(gf, gc, rc, rf, cylo=0, cyhi=None, stream=None):
                               _stream(stream)))
 
 
-def residual_restrict(gf, gc, rc, u, f, cylo=0, cyhi=None, stream=None):
-    check(_fn("residual_restrict", u)(C.byref(gf), C.byref(gc), _p(rc), _p(u), _p(f), cylo,
-                                      gc.ny if cyhi is None else cyhi, _stream(stream)))
-
-
 def correct(gf, gc, out, u, e, ylo=0, yhi=None, stream=None):
     check(_fn("correct", u)(C.byref(gf), C.byref(gc), _p(out), _p(u), _p(e), ylo, gf.ny if yhi is None else yhi,
                             _stream(stream)))
@@ -279,7 +273,7 @@ def box_cells_host(shape, faces=ALL_DIRICHLET):
 class Plan:
     """mgrt_plan: pre-allocated hierarchy; iterate/mg/fmg of MultigridSolver{2,3}D on device arrays."""
 
-    def __init__(self, shape, dtype, faces=ALL_DIRICHLET, zfull=False, use_graph=False, no_fuse=False, stream=None):
+    def __init__(self, shape, dtype, faces=ALL_DIRICHLET, zfull=False, use_graph=False, no_fuse=False, no_bottom=False, stream=None):
         import torch
         d = PlanDesc()
         if len(shape) == 3:
@@ -291,6 +285,7 @@ class Plan:
         d.zfull = int(zfull)
         d.use_graph = int(use_graph)
         d.no_fuse = int(no_fuse)
+        d.no_bottom = int(no_bottom)
         self.shape, self.dtype = tuple(shape), dtype
         self._h = C.c_void_p()
         check(load().mgrt_plan_create(C.byref(self._h), C.byref(d), _stream(stream)))

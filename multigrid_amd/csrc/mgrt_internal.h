@@ -30,11 +30,16 @@ struct Runtime {
     bool ready = false;
     int device = -1;
     int num_cu = 0;
-    double *partials = nullptr; // reduction scratch: one double per block
-    size_t partials_cap = 0;    // entries
 };
 Runtime &runtime();
 mgrt_status require_init();
+
+// Reduction scratch (one double per block, kMaxPartials entries) of the norm kernels.  Every stream
+// has its own array, allocated when the stream first asks, so that norms running on different
+// streams never share partial sums; work on one stream is ordered and shares one array.
+mgrt_status partials_for(hipStream_t s, double **partials);
+void release_partials(hipStream_t s); // the stream is being destroyed
+void release_all_partials();
 
 // Argument validation shared by the kernel launchers.
 mgrt_status check_grid(const mgrt_grid *g, const char *who);
@@ -66,12 +71,19 @@ mgrt_status bottom_cycle(int dim, int nlev, const int *nx, const int *ny, const 
                          double *u, const double *u_in, const double *f, double omega, int a1, int a2, int v,
                          hipStream_t hs);
 
+// The fused 3D sweeps address a z plane with 32-bit byte offsets and use offset 2^31 as the one the
+// hardware range check always drops, so a plane (rows x pitch) must stay below 2 GiB.
+inline bool plane_offsets_fit(const mgrt_grid *g, size_t elem)
+{
+    return (long long)g->pitch * g->ny * (long long)elem < (1LL << 31);
+}
+
 // Whether mgrt_correct_smooth_sweep has a 3D kernel for this level: the plan asks before it drops the
 // separate correction.
 inline bool correct_sweep_3d_supported(const mgrt_grid *g, size_t elem, int iters)
 {
     return g->dim == 3 && elem == 4 && iters == 2 && !g->cells && g->y0 % 2 == 0 && g->nx % 2 == 1 && g->gny % 2 == 1 &&
-           g->nz % 2 == 1 && g->nz >= 5 && !latency_bound_level(*g);
+           g->nz % 2 == 1 && g->nz >= 5 && !latency_bound_level(*g) && plane_offsets_fit(g, elem);
 }
 
 // out = S^iters(in) on a 2D analytic-box grid, iters 1 or 2 (mgrt_smooth2d.hip); in may be null.

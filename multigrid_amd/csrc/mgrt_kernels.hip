@@ -375,172 +375,6 @@ __global__ __launch_bounds__(256) void k_restrict(mgrt_grid fg, mgrt_grid cg, R 
     }
 }
 
-// ---- residual fused with its restriction (3D) ---------------------------------------------------
-// rc = Restrict(f - A u) without ever writing the fine residual: the V-cycle consumes the residual
-// only through the restriction (multigridsolver3D.cpp:61-64), so its N values need not travel to
-// HBM and back.  One thread owns one fine column of a 64 x 9 residual tile and walks a chunk of
-// fine planes with u[z-1], u[z], u[z+1] in registers; every residual plane goes into a 4-deep LDS
-// ring, and after each odd plane 2K+1 the first 31 x 4 threads form coarse plane K from planes
-// 2K-1, 2K, 2K+1 of the ring.  Expressions and operand order are those of residual_kernel
-// (mg_1.cl:46-53,111-133) and reduction_kernel (mg_1.cl:146-190); residual cells the reference
-// never writes (outer, Neumann) count as 0.
-constexpr int kRRX = 64, kRRY = 9, kRRCX = 31, kRRCY = 4;
-template <class R, bool MAP, int KC>
-__global__ __launch_bounds__(kRRX *kRRY) void k_residual_restrict3d(mgrt_grid fg, mgrt_grid cg, R *rc,
-                                                                    const R *__restrict__ u,
-                                                                    const R *__restrict__ f, int cylo, int cyhi,
-                                                                    int ntx, int nty)
-{
-    __shared__ R ring[4][kRRY][kRRX];
-    const int ntiles = ntx * nty;
-    const int t = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int kchunk = t / ntiles, tile = t % ntiles;
-    const int lx = threadIdx.x % kRRX, ly = threadIdx.x / kRRX;
-    const int I0 = (tile % ntx) * kRRCX;
-    const int J0g = cylo + cg.y0 + (tile / ntx) * kRRCY; // global coarse row of the tile's first row
-    const int x = 2 * I0 - 1 + lx;
-    const int y = 2 * J0g - 1 + ly - fg.y0; // local fine row
-    const bool live = x >= 0 && x < fg.nx && y >= 0 && y < fg.ny;
-    const int kb = kchunk * KC, ke = kb + KC < cg.nz ? kb + KC : cg.nz;
-    // fine planes whose residual is needed: 2kb-1 .. 2(ke-1)+1, clipped to the grid
-    const int zb = 2 * kb - 1 > 0 ? 2 * kb - 1 : 0;
-    const int ze = 2 * (ke - 1) + 1 < fg.nz - 1 ? 2 * (ke - 1) + 1 : fg.nz - 1;
-
-    // Plane-relative buffer addressing (see mgrt_device.h): a descriptor per plane in scalar
-    // registers, per-thread byte offsets that never change.  Threads outside the grid use an
-    // offset past the plane, which loads 0; a neighbour offset that leaves the row is only ever
-    // formed for a column on a face, whose cells are not inner and ignore it.
-    constexpr unsigned kDrop = 0x80000000u;
-    const unsigned w = (unsigned)sizeof(R), pb = (unsigned)fg.pitch * w;
-    const unsigned plane_bytes = (unsigned)(fg.pitch * (long long)fg.ny) * w;
-    const unsigned oc = live ? ((unsigned)x + (unsigned)fg.pitch * (unsigned)y) * w : kDrop;
-    const unsigned oxp = live ? oc + w : kDrop, oxm = live ? oc - w : kDrop;
-    const unsigned oyp = live ? oc + pb : kDrop, oym = live ? oc - pb : kDrop;
-    // class of the column where it does not depend on z (lateral face, or OUTER outside), else -1
-    int colcls = -1;
-    if (!live) colcls = MGRT_CELL_OUTER;
-    else if (!MAP) {
-        const int yg = y + fg.y0;
-        if (yg == 0) colcls = fg.face[2];
-        else if (yg == fg.gny - 1) colcls = fg.face[3];
-        else if (x == 0) colcls = fg.face[0];
-        else if (x == fg.nx - 1) colcls = fg.face[1];
-    }
-    const bool col_z = colcls < 0, col_dir = colcls == MGRT_CELL_DIRICHLET;
-    const unsigned char *cellp = MAP && live ? fg.cells + x + (long long)fg.pitch * y : nullptr;
-
-    R um = 0, uc = 0;
-    {
-        const rsrc_t r0 = plane_rsrc(u + fg.slab * zb, plane_bytes);
-        buf_load(uc, r0, oc);
-        if (zb > 0) {
-            const rsrc_t rm = plane_rsrc(u + fg.slab * (zb - 1), plane_bytes);
-            buf_load(um, rm, oc);
-        }
-    }
-
-    // Coarse points are formed by groups of four lanes: lane 0 sums the 8 corners, lane 1 the 12
-    // edges, lane 2 the 6 faces (each in the reference's operand order), lane 3 idles; lane 0 then
-    // combines them.  This spreads the 27 LDS reads of a coarse point over three lanes and over
-    // eight of the block's nine waves instead of leaving them to two.
-    const int cpt = threadIdx.x >> 2, part = threadIdx.x & 3;
-    const int ci = I0 + cpt % kRRCX, cjl = cpt / kRRCX;
-    const int cj = J0g - cg.y0 + cjl;
-    const bool coarse_thread = cpt < kRRCX * kRRCY && ci < cg.nx && cj < cyhi && cj < cg.ny;
-    const int X = 2 * (ci - I0) + 1, Y = 2 * (cjl < kRRCY ? cjl : 0) + 1; // (2I, 2J) inside the tile
-    const int fx = 2 * ci, fy = 2 * (cj + cg.y0) - fg.y0;
-    const bool lat_face = fx == 0 || fx == fg.nx - 1 || fy + fg.y0 == 0 || fy + fg.y0 == fg.gny - 1;
-
-    // Loads run PFD planes ahead of the arithmetic, in registers whose indices are constants after
-    // unrolling.  The coarse store below is hidden from the compiler's wait-count bookkeeping (see
-    // mgrt_device.h): a visible store among the loads would make every wait a full drain.
-    constexpr int PFD = 3;
-    R pup[PFD], pfv[PFD], pxp[PFD], pxm[PFD], pyp[PFD], pym[PFD];
-    auto fetch = [&](int slot, int z) {
-        const int zc = z <= ze ? z : ze;
-        const rsrc_t ru = plane_rsrc(u + fg.slab * zc, plane_bytes), rf = plane_rsrc(f + fg.slab * zc, plane_bytes);
-        const rsrc_t rup = plane_rsrc(u + fg.slab * (zc + 1 < fg.nz ? zc + 1 : zc), plane_bytes);
-        buf_load(pup[slot], rup, oc);
-        buf_load(pfv[slot], rf, oc);
-        buf_load(pxp[slot], ru, oxp);
-        buf_load(pxm[slot], ru, oxm);
-        buf_load(pyp[slot], ru, oyp);
-        buf_load(pym[slot], ru, oym);
-    };
-#pragma unroll
-    for (int k = 0; k < PFD; ++k)
-        fetch(k, zb + k);
-
-    for (int z0 = zb; z0 <= ze; z0 += PFD) {
-#pragma unroll
-      for (int slot = 0; slot < PFD; ++slot) {
-        const int z = z0 + slot;
-        if (z > ze)
-            break;
-        const R up = pup[slot], fv = pfv[slot], xp = pxp[slot], xm = pxm[slot], yp = pyp[slot], ym = pym[slot];
-        fetch(slot, z + PFD);
-        int c;
-        if (MAP)
-            c = live ? cellp[fg.slab * z] : MGRT_CELL_OUTER;
-        else
-            c = col_z ? (z == 0 ? fg.face[4] : (z == fg.nz - 1 ? fg.face[5] : MGRT_CELL_INNER)) : colcls;
-        (void)col_dir;
-        const R ri = fv - (xp + xm + yp + ym + up + um - 6 * uc);
-        const R rd = fv - uc;
-        const R r = c == MGRT_CELL_INNER ? ri : (c == MGRT_CELL_DIRICHLET ? rd : (R)0);
-        um = uc;
-        uc = up;
-        ring[z & 3][ly][lx] = r;
-        __syncthreads();
-        if ((z & 1) && coarse_thread) {
-            const int k = z >> 1; // planes 2k-1, 2k, 2k+1 are in the ring
-            if (k >= kb && k < ke) {
-                const int fz = 2 * k;
-                const R(*m)[kRRX] = ring[(fz - 1) & 3]; // plane below
-                const R(*c0)[kRRX] = ring[fz & 3];
-                const R(*q)[kRRX] = ring[(fz + 1) & 3]; // plane above
-                R part_sum;
-                if (part == 0)
-                    part_sum = q[Y + 1][X + 1] + q[Y + 1][X - 1] + q[Y - 1][X + 1] + q[Y - 1][X - 1] + m[Y + 1][X + 1] +
-                               m[Y + 1][X - 1] + m[Y - 1][X + 1] + m[Y - 1][X - 1];
-                else if (part == 1)
-                    part_sum = c0[Y + 1][X + 1] + c0[Y + 1][X - 1] + c0[Y - 1][X + 1] + c0[Y - 1][X - 1] + m[Y + 1][X] +
-                               m[Y - 1][X] + m[Y][X + 1] + m[Y][X - 1] + q[Y + 1][X] + q[Y - 1][X] + q[Y][X + 1] +
-                               q[Y][X - 1];
-                else
-                    part_sum = c0[Y + 1][X] + c0[Y - 1][X] + c0[Y][X + 1] + c0[Y][X - 1] + q[Y][X] + m[Y][X];
-                // lanes 4n+1 and 4n+2 hand their sums to lane 4n
-                const R edges = __shfl_down(part_sum, 1, 4), faces = __shfl_down(part_sum, 2, 4);
-                if (part == 0) {
-                    // A centre on a face of the grid always injects (see k_restrict); otherwise the
-                    // forward 2x2x2 block is classified in the reference's short-circuit order.
-                    bool border = lat_face || fz == 0 || fz == fg.nz - 1 || is_border(cell_class<3, MAP>(fg, fx, fy, fz));
-                    if (!border)
-                        border = is_border(cell_class<3, MAP>(fg, fx + 1, fy, fz)) ||
-                                 is_border(cell_class<3, MAP>(fg, fx, fy + 1, fz)) ||
-                                 is_border(cell_class<3, MAP>(fg, fx + 1, fy + 1, fz)) ||
-                                 is_border(cell_class<3, MAP>(fg, fx, fy, fz + 1)) ||
-                                 is_border(cell_class<3, MAP>(fg, fx + 1, fy, fz + 1)) ||
-                                 is_border(cell_class<3, MAP>(fg, fx, fy + 1, fz + 1)) ||
-                                 is_border(cell_class<3, MAP>(fg, fx + 1, fy + 1, fz + 1));
-                    const R centre = c0[Y][X];
-                    const R v = border ? centre
-                                       : (R)(1.0 / 64.0 * part_sum + 1.0 / 32.0 * edges + 1.0 / 16.0 * faces +
-                                             1.0 / 8.0 * centre);
-                    store_hidden(rc + (ci + (long long)cg.pitch * cj + cg.slab * k), v);
-                }
-            }
-        }
-      }
-    }
-    // The last coarse plane of an odd-extent grid sits on the top face: injection.
-    if (ke == cg.nz && coarse_thread && part == 0) {
-        const int k = cg.nz - 1;
-        if (2 * k == fg.nz - 1 && k >= kb)
-            rc[ci + (long long)cg.pitch * cj + cg.slab * k] = ring[(2 * k) & 3][Y][X];
-    }
-}
-
 // ---- interpolation (mg_1.cl:200-267, mg_0.cl:167-222) -----------------------------------------
 // dot(real4, real4) evaluated left to right in R: ((a0*b0 + a1*b1) + a2*b2) + a3*b3.
 template <class R> __device__ __forceinline__ R dot4(R a0, R a1, R a2, R a3, R b0, R b1, R b2, R b3)
@@ -833,9 +667,9 @@ mgrt_status smooth(const mgrt_grid *g, R *u, const R *f, R omega, int iters, int
     return MGRT_OK;
 }
 
-template <bool MAX> mgrt_status fold(int nparts, double *out, hipStream_t hs)
+template <bool MAX> mgrt_status fold(const double *parts, int nparts, double *out, hipStream_t hs)
 {
-    k_fold_partials<MAX><<<1, 256, 0, hs>>>(runtime().partials, nparts, out);
+    k_fold_partials<MAX><<<1, 256, 0, hs>>>(parts, nparts, out);
     MGRT_HIP(hipGetLastError());
     return MGRT_OK;
 }
@@ -861,12 +695,14 @@ mgrt_status residual(const mgrt_grid *g, R *r, const R *u, const R *f, int zero_
     const unsigned nbxy = blocks_for(nthreads, 256);
     int zc3 = g->dim == 3 ? z_chunk(nbxy, g->nz, ZC) : 1;
     // with the norm every block leaves a partial sum: longer chunks keep their number within the scratch
-    while (norm2 && g->dim == 3 && zc3 < g->nz && (size_t)nbxy * blocks_for(g->nz, zc3) > runtime().partials_cap)
+    while (norm2 && g->dim == 3 && zc3 < g->nz && (size_t)nbxy * blocks_for(g->nz, zc3) > (size_t)kMaxPartials)
         zc3 *= 2;
     dim3 grid(nbxy * (g->dim == 3 ? blocks_for(g->nz, zc3) : 1));
     const int nparts = (int)grid.x;
-    MGRT_REQUIRE(!norm2 || (size_t)nparts <= runtime().partials_cap, "mgrt_residual: grid too large for the fused norm");
-    double *parts = runtime().partials;
+    MGRT_REQUIRE(!norm2 || (size_t)nparts <= (size_t)kMaxPartials, "mgrt_residual: grid too large for the fused norm");
+    double *parts = nullptr;
+    if (norm2)
+        if (mgrt_status st = partials_for(hs, &parts)) return st;
 #define MGRT_LAUNCH_RES(DIM, MAP, NORM)                                                                      \
     k_residual<R, DIM, MAP, NORM, ZC><<<grid, 256, 0, hs>>>(*g, r, u, f, zero_unwritten, parts, ylo, yhi, nbxy)
 #define MGRT_LAUNCH_RES3(MAP, NORM)                                                                           \
@@ -883,7 +719,7 @@ mgrt_status residual(const mgrt_grid *g, R *r, const R *u, const R *f, int zero_
 #undef MGRT_LAUNCH_RES3
     MGRT_HIP(hipGetLastError());
     if (nrm)
-        return fold<false>(nparts, norm2, hs);
+        return fold<false>(parts, nparts, norm2, hs);
     return MGRT_OK;
 }
 
@@ -930,39 +766,6 @@ mgrt_status restrict_fw(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, c
         if (map) k_restrict<R, 2, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
         else     k_restrict<R, 2, false><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
     }
-    MGRT_HIP(hipGetLastError());
-    return MGRT_OK;
-}
-
-template <class R>
-mgrt_status residual_restrict(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, const R *u, const R *f, int cylo,
-                              int cyhi, mgrt_stream s)
-{
-    if (mgrt_status st = require_init()) return st;
-    if (mgrt_status st = check_pair(fine, coarse, "mgrt_residual_restrict")) return st;
-    MGRT_REQUIRE(rc && u && f, "mgrt_residual_restrict: null field");
-    MGRT_REQUIRE(0 <= cylo && cylo <= cyhi && cyhi <= coarse->ny,
-                 "mgrt_residual_restrict: coarse rows [%d,%d) outside [0,%d)", cylo, cyhi, coarse->ny);
-    if (fine->dim != 3 || fine->nx % 2 == 0 || fine->gny % 2 == 0 || fine->nz % 2 == 0)
-        return fail(MGRT_E_UNSUPPORTED, "mgrt_residual_restrict: 3D grids with odd extents only");
-    if (cylo < cyhi) {
-        // the residual of fine rows 2*jg-1 .. 2*jg+1 is formed here, which reads one row further
-        const int flo = 2 * (cylo + coarse->y0) - fine->y0, fhi = 2 * (cyhi - 1 + coarse->y0) - fine->y0;
-        MGRT_REQUIRE(flo >= 0 && fhi < fine->ny, "mgrt_residual_restrict: fine slab does not hold rows %d..%d",
-                     flo + fine->y0, fhi + fine->y0);
-        MGRT_REQUIRE((flo >= 2 || flo + fine->y0 == 0) && (fhi + 2 < fine->ny || fhi + fine->y0 == fine->gny - 1),
-                     "mgrt_residual_restrict: fine slab lacks the two halo rows of the requested coarse rows");
-    } else {
-        return MGRT_OK;
-    }
-    constexpr int KC = 32;
-    const int ntx = (coarse->nx + kRRCX - 1) / kRRCX, nty = (cyhi - cylo + kRRCY - 1) / kRRCY;
-    const dim3 grid((unsigned)(ntx * nty) * blocks_for(coarse->nz, KC));
-    hipStream_t hs = (hipStream_t)s;
-    if (fine->cells)
-        k_residual_restrict3d<R, true, KC><<<grid, kRRX * kRRY, 0, hs>>>(*fine, *coarse, rc, u, f, cylo, cyhi, ntx, nty);
-    else
-        k_residual_restrict3d<R, false, KC><<<grid, kRRX * kRRY, 0, hs>>>(*fine, *coarse, rc, u, f, cylo, cyhi, ntx, nty);
     MGRT_HIP(hipGetLastError());
     return MGRT_OK;
 }
@@ -1055,13 +858,15 @@ mgrt_status norm(const mgrt_grid *g, const R *x, double *out, int ylo, int yhi, 
     const unsigned gx = blocks_for(n, 256);
     // keep the number of partials bounded: deepen the z chunk as needed
     int zc = 16;
-    while ((long long)gx * blocks_for(g->nz, zc) > (long long)runtime().partials_cap)
+    while ((long long)gx * blocks_for(g->nz, zc) > (long long)kMaxPartials)
         zc *= 2;
     dim3 grid(gx, blocks_for(g->nz, zc));
-    MGRT_REQUIRE((size_t)grid.x * grid.y <= runtime().partials_cap, "%s: grid too large", who);
-    k_norm_partials<R, MAX><<<grid, 256, 0, hs>>>(*g, x, runtime().partials, ylo, yhi, zc);
+    MGRT_REQUIRE((size_t)grid.x * grid.y <= (size_t)kMaxPartials, "%s: grid too large", who);
+    double *parts = nullptr;
+    if (mgrt_status st = partials_for(hs, &parts)) return st;
+    k_norm_partials<R, MAX><<<grid, 256, 0, hs>>>(*g, x, parts, ylo, yhi, zc);
     MGRT_HIP(hipGetLastError());
-    return fold<MAX>((int)(grid.x * grid.y), out, hs);
+    return fold<MAX>(parts, (int)(grid.x * grid.y), out, hs);
 }
 
 // Blocking: allocates the tree's intermediate arrays like the reference does (auxiliary.cpp:124).
@@ -1133,9 +938,6 @@ template <class R, int MODE> mgrt_status reftree(const R *x, long long n, R *res
     extern "C" mgrt_status mgrt_restrict##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, const R *rf, \
                                             int cylo, int cyhi, mgrt_stream s)                                 \
     { return restrict_fw<R>(fine, coarse, rc, rf, cylo, cyhi, s); }                                            \
-    extern "C" mgrt_status mgrt_residual_restrict##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc,        \
-                                                     const R *u, const R *f, int cylo, int cyhi, mgrt_stream s) \
-    { return residual_restrict<R>(fine, coarse, rc, u, f, cylo, cyhi, s); }                                    \
     extern "C" mgrt_status mgrt_correct##S(const mgrt_grid *fine, const mgrt_grid *coarse, R *out, const R *u,  \
                                            const R *e, int ylo, int yhi, mgrt_stream s)                        \
     { return interp<R, 0>(fine, coarse, out, u, e, ylo, yhi, s); }                                             \

@@ -5,7 +5,6 @@
 // every work array allocated once at plan creation instead of three cl::Buffers per level per call
 // (multigridsolver3D.cpp:53-55), and the whole cycle optionally replayed from a hipGraph.
 #include "mgrt_internal.h"
-#include <cstdlib>
 #include <vector>
 
 using namespace mgrt;
@@ -25,12 +24,6 @@ struct mgrt_plan {
         size_t n = 0;
     };
     std::vector<Level> lv;
-    // residual and restriction in one kernel (no residual array traffic).  Off by default: as
-    // measured at 513^3 the two streaming kernels together are faster than the fused one.
-    // MGRT_FUSE_RESIDUAL_RESTRICT=1 in the environment at plan creation turns it on.
-    bool fuse_rr = false;
-    // run the coarsest levels as one launch (mgrt_bottom.hip); MGRT_NO_BOTTOM=1 turns it off
-    bool use_bottom = true;
     double *d_norms = nullptr; // device: residual norms of a run
     int norms_cap = 0;
     // cached graph of one iterate() call
@@ -75,7 +68,6 @@ template <> struct K<float> {
     static constexpr auto sweep_res_restrict = mgrt_smooth_sweep_residual_restrict_f32;
     static constexpr auto residual = mgrt_residual_f32;
     static constexpr auto restrict_ = mgrt_restrict_f32;
-    static constexpr auto resrestrict = mgrt_residual_restrict_f32;
     static constexpr auto correct = mgrt_correct_f32;
     static constexpr auto prolong = mgrt_prolong_f32;
 };
@@ -87,7 +79,6 @@ template <> struct K<double> {
     static constexpr auto sweep_res_restrict = mgrt_smooth_sweep_residual_restrict_f64;
     static constexpr auto residual = mgrt_residual_f64;
     static constexpr auto restrict_ = mgrt_restrict_f64;
-    static constexpr auto resrestrict = mgrt_residual_restrict_f64;
     static constexpr auto correct = mgrt_correct_f64;
     static constexpr auto prolong = mgrt_prolong_f64;
 };
@@ -97,7 +88,7 @@ template <> struct K<double> {
 int bottom_from(const mgrt_plan *p)
 {
     const int n = (int)p->lv.size();
-    if (!p->use_bottom || p->desc.no_fuse)
+    if (p->desc.no_bottom || p->desc.no_fuse)
         return n;
     int first = n;
     for (int l = n - 1; l >= 0; --l) {
@@ -125,7 +116,10 @@ mgrt_status run_bottom(mgrt_plan *p, int l, R *u, const R *u_in, const R *f, R o
 
 // The fused sweep kernels cover analytic-box levels; levels with a byte map smooth in place with
 // the single-colour kernel.
-bool sweepable(const mgrt_plan *p, const mgrt_grid &g) { return !p->desc.no_fuse && g.cells == nullptr; }
+bool sweepable(const mgrt_plan *p, const mgrt_grid &g)
+{
+    return !p->desc.no_fuse && g.cells == nullptr && (g.dim == 2 || plane_offsets_fit(&g, (size_t)p->desc.elem_size));
+}
 
 // `a` smoothing iterations on *cur, as `nsweeps` out-of-place fused sweeps that ping-pong between
 // *cur and *alt (nsweeps between ceil(a/2) and a), or in place when nsweeps == 0.  With `res`, the
@@ -193,10 +187,10 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
     // precision when that sweep does two iterations.
     const bool res_in_sweep =
         n1 > 0 && v > 0 && recurses(L.g) &&
-        (L.g.dim == 2 || (sizeof(R) == 4 && L.g.dim == 3 && !latency_bound_level(L.g) && !p->fuse_rr));
+        (L.g.dim == 2 || (sizeof(R) == 4 && L.g.dim == 3 && !latency_bound_level(L.g)));
     const bool correct_in_sweep =
         n2 > 0 && a2 > 0 && v > 0 && recurses(L.g) &&
-        (L.g.dim == 2 || (!p->fuse_rr && correct_sweep_3d_supported(&L.g, sizeof(R), n2 < a2 ? 2 : 1)));
+        (L.g.dim == 2 || correct_sweep_3d_supported(&L.g, sizeof(R), n2 < a2 ? 2 : 1));
     // 2D: that sweep hands the coarse level its right-hand side directly (no fine residual array)
     const bool restrict_in_sweep = res_in_sweep && L.g.dim == 2;
     if (a1 > 0) {
@@ -210,17 +204,12 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
         for (int k = 0; k < v; ++k) {
             // outer/Neumann cells of the residual are defined as 0 (the reference reads
             // uninitialised memory there)
-            if (L.g.dim == 3 && p->fuse_rr) {
-                if (mgrt_status st = K<R>::resrestrict(&L.g, &C.g, (R *)C.rhs, cur, f, 0, C.g.ny, s))
+            if (!(res_in_sweep && k == 0))
+                if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, 0, L.g.ny, s))
                     return st;
-            } else {
-                if (!(res_in_sweep && k == 0))
-                    if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, 0, L.g.ny, s))
-                        return st;
-                if (!(restrict_in_sweep && k == 0))
-                    if (mgrt_status st = K<R>::restrict_(&L.g, &C.g, (R *)C.rhs, (const R *)L.r, 0, C.g.ny, s))
-                        return st;
-            }
+            if (!(restrict_in_sweep && k == 0))
+                if (mgrt_status st = K<R>::restrict_(&L.g, &C.g, (R *)C.rhs, (const R *)L.r, 0, C.g.ny, s))
+                    return st;
             if (mgrt_status st = iterate<R>(p, l + 1, (R *)C.e, (const R *)C.rhs, omega, a1, a2, v, true)) // zero_mem(i), :59
                 return st;
             // in place: same values as the out-of-place kernel followed by the handle swap (:70-72)
@@ -388,15 +377,17 @@ mgrt_status mgrt_plan_create(mgrt_plan **plan, const mgrt_plan_desc *d, mgrt_str
         if (d->dim == 3)
             nz = (nz + 1) / 2;
     }
-    if (const char *e = getenv("MGRT_NO_BOTTOM"))
-        p->use_bottom = e[0] != '1';
-    if (const char *e = getenv("MGRT_FUSE_RESIDUAL_RESTRICT"))
-        p->fuse_rr = !d->no_fuse && e[0] == '1';
+    // the norm scratch of this plan's stream exists before any cycle is captured into a graph
+    double *parts = nullptr;
+    if (mgrt_status st = partials_for(p->stream, &parts)) {
+        delete p;
+        return st;
+    }
     const size_t w = (size_t)d->elem_size;
     for (size_t l = 0; l < p->lv.size(); ++l) {
         mgrt_plan::Level &L = p->lv[l];
         hipError_t e = hipSuccess;
-        if (l + 1 < p->lv.size())
+        if (l + 1 < p->lv.size() || l == 0) // level 0: also the target of the residual history
             e = hipMalloc(&L.r, L.n * w);
         if (e == hipSuccess && !d->no_fuse)
             e = hipMalloc(&L.work, L.n * w);
@@ -475,6 +466,7 @@ mgrt_status mgrt_plan_vcycle(mgrt_plan *p, void *u, const void *f, double omega,
 {
     if (mgrt_status st = require_init()) return st;
     MGRT_REQUIRE(p && u && f, "mgrt_plan_vcycle: null argument");
+    MGRT_REQUIRE(u != f, "mgrt_plan_vcycle: u and f are the same array");
     MGRT_REQUIRE(a1 >= 0 && a2 >= 0 && v >= 0 && ncycles >= 0, "mgrt_plan_vcycle: negative count");
     if (p->desc.elem_size == 4)
         return vcycle<float>(p, (float *)u, (const float *)f, (float)omega, a1, a2, v, ncycles, res_hist);
@@ -485,6 +477,7 @@ mgrt_status mgrt_plan_fmg(mgrt_plan *p, void *u_out, const void *f, double omega
 {
     if (mgrt_status st = require_init()) return st;
     MGRT_REQUIRE(p && u_out && f, "mgrt_plan_fmg: null argument");
+    MGRT_REQUIRE(u_out != f, "mgrt_plan_fmg: u_out and f are the same array");
     MGRT_REQUIRE(a1 >= 0 && a2 >= 0 && v >= 0 && iters >= 0, "mgrt_plan_fmg: negative count");
     p->bottom = bottom_from(p);
     if (p->desc.elem_size == 4)

@@ -5,6 +5,8 @@
 // status codes instead of exceptions.
 #include "mgrt_internal.h"
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 namespace mgrt {
 
@@ -23,6 +25,42 @@ Runtime &runtime()
 {
     static Runtime rt;
     return rt;
+}
+
+namespace {
+std::mutex g_partials_mutex;
+std::unordered_map<hipStream_t, double *> g_partials;
+} // namespace
+
+mgrt_status partials_for(hipStream_t s, double **partials)
+{
+    std::lock_guard<std::mutex> lock(g_partials_mutex);
+    auto it = g_partials.find(s);
+    if (it == g_partials.end()) {
+        double *p = nullptr;
+        MGRT_HIP(hipMalloc((void **)&p, sizeof(double) * kMaxPartials));
+        it = g_partials.emplace(s, p).first;
+    }
+    *partials = it->second;
+    return MGRT_OK;
+}
+
+void release_partials(hipStream_t s)
+{
+    std::lock_guard<std::mutex> lock(g_partials_mutex);
+    auto it = g_partials.find(s);
+    if (it != g_partials.end()) {
+        (void)hipFree(it->second);
+        g_partials.erase(it);
+    }
+}
+
+void release_all_partials()
+{
+    std::lock_guard<std::mutex> lock(g_partials_mutex);
+    for (auto &kv : g_partials)
+        (void)hipFree(kv.second);
+    g_partials.clear();
 }
 
 mgrt_status require_init()
@@ -79,8 +117,6 @@ mgrt_status mgrt_init(int device)
         return fail(MGRT_E_NO_DEVICE, "device %d is %s; this library holds gfx950 code only", device,
                     prop.gcnArchName);
     rt.num_cu = prop.multiProcessorCount;
-    MGRT_HIP(hipMalloc((void **)&rt.partials, sizeof(double) * kMaxPartials));
-    rt.partials_cap = kMaxPartials;
     rt.device = device;
     rt.ready = true;
     return MGRT_OK;
@@ -92,7 +128,7 @@ mgrt_status mgrt_shutdown(void)
     if (!rt.ready)
         return MGRT_OK;
     MGRT_HIP(hipDeviceSynchronize());
-    MGRT_HIP(hipFree(rt.partials));
+    release_all_partials();
     rt = Runtime();
     return MGRT_OK;
 }
@@ -166,8 +202,11 @@ mgrt_status mgrt_stream_create(mgrt_stream *s)
 
 mgrt_status mgrt_stream_destroy(mgrt_stream s)
 {
-    if (s)
+    if (s) {
+        MGRT_HIP(hipStreamSynchronize((hipStream_t)s));
+        release_partials((hipStream_t)s);
         MGRT_HIP(hipStreamDestroy((hipStream_t)s));
+    }
     return MGRT_OK;
 }
 

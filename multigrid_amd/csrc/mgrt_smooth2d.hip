@@ -238,17 +238,6 @@ mgrt_status launch2d_cols(const mgrt_grid *g, const mgrt_grid *cg, R *out, R *re
     return MGRT_OK;
 }
 
-#ifdef MGRT_TUNE
-int tuned_rows(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-#define MGRT_ROWS(name, dflt) tuned_rows(name, dflt)
-#else
-#define MGRT_ROWS(name, dflt) (dflt)
-#endif
-
 // Tile heights measured on V(2,2) cycles: 20 rows from 2049^2 up; below, 12 rows, or 14 with the
 // wider halo of the residual variant; 24 and 16 with the restriction.
 template <class R, int ITERS, Input IN, int RES>
@@ -257,27 +246,13 @@ mgrt_status sweep2d(const mgrt_grid *g, const mgrt_grid *cg, R *out, R *res, con
 {
     const bool large = (long long)g->nx * g->ny >= 1500LL * 1500LL;
     if constexpr (RES == 2) {
-        const int rt = MGRT_ROWS("MGRT_2D_ROWS_RST", large ? 24 : 16);
-#ifdef MGRT_TUNE
-        if (rt == 20) return launch2d_cols<R, ITERS, 20, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
-        if (rt == 28) return launch2d_cols<R, ITERS, 28, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
-#endif
-        if (rt == 16) return launch2d_cols<R, ITERS, 16, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+        if (!large) return launch2d_cols<R, ITERS, 16, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
         return launch2d_cols<R, ITERS, 24, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
     } else if constexpr (RES == 1) {
-        const int rt = MGRT_ROWS("MGRT_2D_ROWS_RES", large ? 20 : 14);
-#ifdef MGRT_TUNE
-        if (rt == 16) return launch2d_cols<R, ITERS, 16, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
-        if (rt == 24) return launch2d_cols<R, ITERS, 24, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
-#endif
-        if (rt == 14) return launch2d_cols<R, ITERS, 14, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+        if (!large) return launch2d_cols<R, ITERS, 14, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
         return launch2d_cols<R, ITERS, 20, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
     } else {
-        const int rt = MGRT_ROWS("MGRT_2D_ROWS", large ? 20 : 12);
-#ifdef MGRT_TUNE
-        if (rt == 16) return launch2d_cols<R, ITERS, 16, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
-#endif
-        if (rt == 12) return launch2d_cols<R, ITERS, 12, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
+        if (!large) return launch2d_cols<R, ITERS, 12, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
         return launch2d_cols<R, ITERS, 20, IN, RES>(g, cg, out, res, in, e, f, omega, hs);
     }
 }

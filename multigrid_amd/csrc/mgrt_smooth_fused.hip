@@ -33,7 +33,6 @@
 #include "mgrt_internal.h"
 #include "mgrt_device.h"
 #include <type_traits>
-#include <cstdlib>
 
 using namespace mgrt;
 
@@ -519,7 +518,6 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
     MGRT_REQUIRE(out != in && out != f, "mgrt_smooth_sweep: out must not alias in or f");
     MGRT_REQUIRE(!res || (res != out && res != in && res != f), "mgrt_smooth_sweep_residual: r must not alias another field");
     MGRT_REQUIRE(zcount >= 0 && zcount <= g->nz, "mgrt_smooth_sweep: zcount %d outside [0,%d]", zcount, g->nz);
-    MGRT_REQUIRE(g->slab < (1LL << 30), "mgrt_smooth_sweep: plane too large for 32-bit in-plane offsets");
     if (g->cells)
         return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep: byte cell maps are not supported, use mgrt_smooth_pass");
     if (iters != 1 && iters != 2)
@@ -527,77 +525,12 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
     hipStream_t hs = (hipStream_t)s;
     if (g->dim != 3)
         return smooth_sweep_2d(g, nullptr, out, res, in, nullptr, f, omega, iters, hs);
+    if (!plane_offsets_fit(g, sizeof(R)))
+        return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep: a z plane of 2 GiB or more is beyond the 32-bit in-plane "
+                                        "offsets of this kernel, use mgrt_smooth_pass");
     using C = Cfg<R>;
-#ifdef MGRT_TUNE
-    // development only: pick a tile shape at run time
-    if (const char *e = getenv("MGRT_SWEEP_CFG")) {
-        const int c = atoi(e);
-        if (sizeof(R) == 4 && iters == 2) {
-            switch (c) {
-            case 1: return launch<R, 2, 4, 8, 2>(g, out, in, f, omega, zcount, hs);
-            case 2: return launch<R, 2, 4, 6, 3>(g, out, in, f, omega, zcount, hs);
-            case 3: return launch<R, 2, 2, 16, 6>(g, out, in, f, omega, zcount, hs);
-            case 4: return launch<R, 2, 2, 8, 3>(g, out, in, f, omega, zcount, hs);
-            case 5: return launch<R, 2, 4, 16, 3>(g, out, in, f, omega, zcount, hs);
-            case 6: return launch<R, 2, 2, 12, 6>(g, out, in, f, omega, zcount, hs);
-            case 7: return launch<R, 2, 4, 12, 3>(g, out, in, f, omega, zcount, hs);
-            case 8: return launch<R, 2, 6, 6, 3>(g, out, in, f, omega, zcount, hs);
-            case 9: return launch<R, 2, 4, 4, 3>(g, out, in, f, omega, zcount, hs);
-            case 10: return launch<R, 2, 6, 4, 3>(g, out, in, f, omega, zcount, hs);
-            case 11: return launch<R, 2, 4, 3, 3>(g, out, in, f, omega, zcount, hs);
-            case 12: return launch<R, 2, 8, 2, 2>(g, out, in, f, omega, zcount, hs);
-            case 13: return launch<R, 2, 4, 5, 3>(g, out, in, f, omega, zcount, hs);
-            case 14: return launch<R, 2, 4, 5, 2>(g, out, in, f, omega, zcount, hs);
-            case 15: return launch<R, 2, 4, 6, 3>(g, out, in, f, omega, zcount, hs);
-            case 16: return launch<R, 2, 4, 7, 3>(g, out, in, f, omega, zcount, hs);
-            }
-        }
-        if (sizeof(R) == 8 && iters == 2) {
-            switch (c) {
-            case 1: return launch<R, 2, 2, 8, 3>(g, out, in, f, omega, zcount, hs);
-            case 2: return launch<R, 2, 2, 16, 3>(g, out, in, f, omega, zcount, hs);
-            case 3: return launch<R, 2, 2, 12, 2>(g, out, in, f, omega, zcount, hs);
-            case 4: return launch<R, 2, 2, 12, 6>(g, out, in, f, omega, zcount, hs);
-            case 5: return launch<R, 2, 4, 4, 3>(g, out, in, f, omega, zcount, hs);
-            case 6: return launch<R, 2, 4, 8, 2>(g, out, in, f, omega, zcount, hs);
-            case 7: return launch<R, 2, 4, 6, 3>(g, out, in, f, omega, zcount, hs);
-            }
-        }
-        if (sizeof(R) == 4 && iters == 1) {
-            switch (c) {
-            case 1: return launch<R, 1, 4, 4, 4>(g, out, in, f, omega, zcount, hs);
-            case 2: return launch<R, 1, 2, 8, 8>(g, out, in, f, omega, zcount, hs);
-            case 3: return launch<R, 1, 2, 16, 4>(g, out, in, f, omega, zcount, hs);
-            case 4: return launch<R, 1, 8, 4, 2>(g, out, in, f, omega, zcount, hs);
-            case 5: return launch<R, 1, 4, 16, 4>(g, out, in, f, omega, zcount, hs);
-            case 6: return launch<R, 1, 8, 8, 2>(g, out, in, f, omega, zcount, hs);
-            case 9: return launch<R, 1, 2, 4, 4>(g, out, in, f, omega, zcount, hs);
-            case 10: return launch<R, 1, 4, 2, 4>(g, out, in, f, omega, zcount, hs);
-            case 11: return launch<R, 1, 4, 4, 4>(g, out, in, f, omega, zcount, hs);
-            case 12: return launch<R, 1, 2, 6, 4>(g, out, in, f, omega, zcount, hs);
-            }
-        }
-    }
-#endif
     // strips of two rows halve the work a wave does per step (measured 25-30 % faster from 257^2 down)
     const bool small = latency_bound_level(*g);
-#ifdef MGRT_TUNE
-    if (const char *e = getenv("MGRT_SWEEP_CFG")) {
-        if (res && sizeof(R) == 4 && iters == 2) {
-            switch (atoi(e)) {
-            case 1: return launch<R, 2, 4, 8, 2, true>(g, out, in, f, omega, zcount, hs, res);
-            case 2: return launch<R, 2, 4, 6, 2, true>(g, out, in, f, omega, zcount, hs, res);
-            case 3: return launch<R, 2, 4, 6, 4, true>(g, out, in, f, omega, zcount, hs, res);
-            case 4: return launch<R, 2, 4, 5, 2, true>(g, out, in, f, omega, zcount, hs, res);
-            case 5: return launch<R, 2, 4, 7, 2, true>(g, out, in, f, omega, zcount, hs, res);
-            case 6: return launch<R, 2, 4, 10, 2, true>(g, out, in, f, omega, zcount, hs, res);
-            case 7: return launch<R, 2, 2, 8, 2, true>(g, out, in, f, omega, zcount, hs, res);
-            case 8: return launch<R, 2, 4, 4, 2, true>(g, out, in, f, omega, zcount, hs, res);
-            case 9: return launch<R, 2, 6, 6, 2, true>(g, out, in, f, omega, zcount, hs, res);
-            }
-        }
-    }
-#endif
     if (res) {
         // Strips of four rows only with 4-byte elements (registers).  Shapes chosen by timing whole
         // cycles: kernel-only timings on warm caches favour other shapes that lose in the cycle.
@@ -644,8 +577,6 @@ mgrt_status correct_smooth_sweep(const mgrt_grid *fine, const mgrt_grid *coarse,
         if (!correct_sweep_3d_supported(fine, sizeof(R), iters))
             return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: in 3D, 4-byte elements, iters == 2, odd extents, an "
                                             "even slab offset and more than 300^2 columns only");
-        MGRT_REQUIRE(fine->slab < (1LL << 30) && coarse->slab < (1LL << 30),
-                     "mgrt_correct_smooth_sweep: plane too large for 32-bit in-plane offsets");
         if constexpr (sizeof(R) == 4) {
             using C = Cfg<R>;
             return launch<R, 2, C::SR2, C::NW2, C::PF2, false, true>(fine, out, u, f, omega, zcount, (hipStream_t)s, nullptr,

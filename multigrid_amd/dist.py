@@ -309,5 +309,10 @@ class SlabCycle:
             dist.all_reduce(self.norm, group=self.group)
         return float(self.norm.item()) ** 0.5
 
+    def describe(self):
+        """The decomposition, for reports."""
+        return {"slab_rows": [b - a for a, b in zip(self.bounds, self.bounds[1:])], "halo_rows": HALO,
+                "distributed_levels": self.ndist, "replicated_from": "x".join(map(str, self.coarse_shape))}
+
     def close(self):
         self.coarse_plan.close()

@@ -100,6 +100,7 @@ mgrt_plan *SolverCore::planFor(const Dims &n)
     d.zfull = fullZRange ? 1 : 0;
     d.use_graph = useGraph ? 1 : 0;
     d.no_fuse = 0;
+    d.no_bottom = 0;
     const mgrt_grid top = describe(n);
     for (int i = 0; i < 6; ++i)
         d.face[i] = top.face[i];

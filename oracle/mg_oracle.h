@@ -93,6 +93,12 @@ void MGO_NAME(box_cells)(int dim, uint8_t *cell, int nx, int ny, int nz, const i
  * BorderHandler3D::cellType (multigridsolver3D.h:32). */
 typedef int (*mgo_celltype_fn)(int x, int y, int z, int nx, int ny, int nz);
 void MGO_NAME(set_celltype)(mgo_celltype_fn fn);
+/* The same with a rule built into the library: 0 = none (box), 1 = the ball inscribed in the box
+ * (inner core, a shell that is Dirichlet on the low-x side and Neumann on the other, outer cells
+ * around it).  For cases too large for a callback per point. */
+void MGO_NAME(set_builtin_celltype)(int kind);
+/* copy of the cell map the host drivers use on a level of these extents under the active rule */
+void MGO_NAME(copy_level_cells)(int dim, uint8_t *out, int nx, int ny, int nz);
 
 /* Problem setup restated from functionhandler.cpp:25-101 and programstate.cpp:84-122.
  * problem: 0 = 3D tridimF1/tridimS1, 1 = 2D sinfunc2/sinfunc2sol, 2 = 2D sinfunc1/sinfunc1sol.

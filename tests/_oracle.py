@@ -47,6 +47,8 @@ class Oracle:
             self._sig("l2norm_exact" + S, C.c_double, [p, l])
         self._sig("box_cells", None, [i, p, i, i, i, C.POINTER(C.c_int)])
         self._sig("set_celltype", None, [C.c_void_p])
+        self._sig("set_builtin_celltype", None, [i])
+        self._sig("copy_level_cells", None, [i, p, i, i, i])
         self._sig("num_threads", i, [])
         self._sig("set_num_threads", None, [i])
 
@@ -141,18 +143,17 @@ class Oracle:
         self._pyfn = fn
         self._set_celltype(C.cast(self._cb, C.c_void_p) if self._cb else None)
 
+    def set_builtin_celltype(self, kind):
+        """kind 1: the ball rule compiled into the oracle (no callback per point); 0: back to the box."""
+        self._cb = self._pyfn = None
+        self._set_builtin_celltype(kind)
+
     def level_cells(self, shape):
-        """The byte map of a grid under the active cell rule (set_celltype), as the cycle drivers see it."""
-        fn = getattr(self, "_pyfn", None)
-        if fn is None:
-            return self.box_cells(shape)
+        """The byte map of a grid under the active cell rule, as the cycle drivers see it."""
         dim, nx, ny, nz = self._dims(shape)
-        cell = np.empty((nz, ny, nx), dtype=np.uint8)
-        for z in range(nz):
-            for y in range(ny):
-                for x in range(nx):
-                    cell[z, y, x] = fn(x, y, z, nx, ny, nz)
-        return cell.reshape(shape)
+        cell = np.empty(shape, dtype=np.uint8)
+        self._copy_level_cells(dim, _ptr(cell), nx, ny, nz)
+        return cell
 
     def discretize(self, problem, shape, dtype):
         """problem 0: 3D tridimF1/tridimS1; 1: 2D sinfunc2; 2: 2D sinfunc1 -> (func, sol)"""

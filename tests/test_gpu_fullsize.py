@@ -131,3 +131,61 @@ def test_plan_paths_agree_on_anisotropic_grids(dev, case):
         outs.append(u)
     assert torch.equal(outs[0].view(torch.uint8), outs[1].view(torch.uint8))
     assert torch.isfinite(outs[0]).all()
+
+
+def oracle_cycle(mgo, shape, dt, cycles=1):
+    """V(2,2) cycles of the reference's 3D problem (tridimF1, programstate.cpp:114-122) from a zero
+    guess on the CPU oracle, all z planes smoothed.  Returns (f, u)."""
+    f, _ = mgo.discretize(0, shape, dt)
+    u = np.zeros(shape, dt)
+    mgo.mg(u, f, dt(1.0), 2, 2, 1, cycles, True)
+    return f, u
+
+
+def gpu_cycle(dev, f, cycles=1, maps=None, **kw):
+    import torch
+    from multigrid_amd import _lib as L
+    df = torch.from_numpy(f).to(dev)
+    du = torch.zeros_like(df)
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        plan = L.Plan(tuple(f.shape), df.dtype, zfull=True, **kw)
+        if maps is not None:
+            for l in range(plan.levels):
+                plan.set_cells(l, maps(plan.level_shape(l)))
+        plan.vcycle(du, df, 1.0, 2, 2, 1, cycles)
+        plan.close()
+    torch.cuda.synchronize()
+    return du.cpu().numpy()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
+def test_257_cubed_cycle_matches_oracle(dev, mgo, dt):
+    """One whole V(2,2) cycle at 257^3 (fused sweeps, graph replay, one-launch bottom) against the
+    CPU oracle, bit for bit."""
+    f, ref = oracle_cycle(mgo, (257, 257, 257), dt, cycles=2)
+    got = gpu_cycle(dev, f, cycles=2, use_graph=True)
+    assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+
+
+def test_513_cubed_f32_cycle_matches_oracle(dev, mgo):
+    """The benchmark's own workload: one V(2,2) cycle at 513^3 in float against the CPU oracle, bit
+    for bit (this is the path with the residual pass and the correction inside the sweeps)."""
+    f, ref = oracle_cycle(mgo, (513, 513, 513), np.float32)
+    got = gpu_cycle(dev, f, use_graph=True)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_257_cubed_ball_domain_matches_oracle(dev, mgo):
+    """A domain that is not a box, at 257^3: the ball inscribed in the cube with a Dirichlet /
+    Neumann shell and outer cells around it, described by one byte per point on every level."""
+    shape = (257, 257, 257)
+    mgo.set_builtin_celltype(1)
+    try:
+        f, ref = oracle_cycle(mgo, shape, np.float32)
+        got = gpu_cycle(dev, f, maps=mgo.level_cells, use_graph=True)
+    finally:
+        mgo.set_builtin_celltype(0)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert np.abs(ref).max() > 0

@@ -162,34 +162,6 @@ def test_fused_sweep_matches_oracle(dev, mgo, dt, shape):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
-@pytest.mark.parametrize("shape", [(9, 11, 13), (5, 5, 5), (3, 3, 3), (33, 17, 65), (17, 131, 71), (41, 61, 59),
-                                   (7, 25, 121), (21, 9, 129)],
-                         ids=lambda s: "x".join(map(str, s[::-1])))
-def test_fused_residual_restrict_matches_oracle(dev, mgo, dt, shape):
-    """Restrict(f - A u) in one kernel against the oracle's residual followed by its restriction."""
-    import torch
-    from multigrid_amd import _lib as L
-    rng = np.random.default_rng(abs(hash((shape, dt.__name__, "rr"))) % 2**32)
-    cs = tuple((s + 1) // 2 for s in shape)
-    variants = [(mgo.box_cells(shape), None, (2,) * 6), (mgo.box_cells(shape, (2, 3, 3, 2, 2, 3)), None, (2, 3, 3, 2, 2, 3))]
-    if min(shape) >= 5:
-        c = random_cells(mgo, rng, shape)
-        variants.append((c, c, (2,) * 6))
-    for cell, dmap, faces in variants:
-        dcell = to_dev(dmap, dev) if dmap is not None else None
-        g, gc = L.grid(shape, cells=dcell, faces=faces), L.grid(cs)
-        u = rng.standard_normal(shape).astype(dt)
-        f = rng.standard_normal(shape).astype(dt)
-        r = np.zeros(shape, dt)
-        mgo.residual(cell, r, u, f)
-        ref = np.zeros(cs, dt)
-        mgo.restrict(cell, ref, r)
-        out = torch.full(cs, 99.0, dtype=to_dev(u, dev).dtype, device=dev)
-        L.residual_restrict(g, gc, out, to_dev(u, dev), to_dev(f, dev))
-        assert bits_equal(out.cpu().numpy(), ref), (shape, faces, dmap is not None)
-
-
-@pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("shape", [(9, 11, 13), (5, 5, 5), (33, 17, 65), (20, 67, 129), (17, 130, 70), (40, 60, 58),
                                    (70, 140, 150)],
                          ids=lambda s: "x".join(map(str, s[::-1])))
@@ -572,6 +544,72 @@ def test_cycle_with_cell_maps_matches_oracle(dev, mgo, dt):
         plan.close()
     finally:
         mgo.set_celltype(None)
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 3), (3, 9), (5, 3, 9)], ids=lambda s: "x".join(map(str, s[::-1])))
+def test_grid_that_does_not_recurse_with_history(dev, mgo, shape):
+    """A grid with an extent of 3 is a single level: smoothing only (multigridsolver3D.cpp:51), and
+    the residual history still works."""
+    import torch
+    from multigrid_amd import _lib as L
+    rng = np.random.default_rng(11)
+    f = rng.standard_normal(shape).astype(np.float32)
+    u = rng.standard_normal(shape).astype(np.float32)
+    ref = u.copy()
+    mgo.mg(ref, f, np.float32(0.8), 2, 1, 1, 2, True)
+    r = np.zeros(shape, np.float32)
+    mgo.residual(mgo.box_cells(shape), r, ref, f)
+    du, df = to_dev(u, dev), to_dev(f, dev)
+    plan = L.Plan(shape, torch.float32, zfull=True)
+    assert plan.levels == 1
+    hist = plan.vcycle(du, df, 0.8, 2, 1, 1, 2, history=True)
+    assert bits_equal(du.cpu().numpy(), ref)
+    assert abs(hist[-1] - mgo.l2norm_exact(r)) <= 1e-12 * hist[-1]
+    with pytest.raises(L.MgrtError):
+        plan.vcycle(du, du)
+    plan.close()
+
+
+def test_two_plans_on_two_streams_keep_their_norms_apart(dev):
+    """Residual histories of two plans that run at the same time on different streams equal the
+    histories of the same plans run one after the other: the reduction scratch is per stream."""
+    import torch
+    from multigrid_amd import _lib as L
+    shapes = [(129, 129, 129), (65, 129, 257)]
+    torch.manual_seed(2)
+    fs = [torch.randn(s, device=dev) for s in shapes]
+    streams = [torch.cuda.Stream() for _ in shapes]
+    torch.cuda.synchronize()
+
+    def make(i):
+        with torch.cuda.stream(streams[i]):
+            return L.Plan(shapes[i], torch.float32, zfull=True, stream=streams[i].cuda_stream)
+
+    serial = []
+    for i in range(2):
+        plan, u = make(i), torch.zeros_like(fs[i])
+        serial.append(plan.vcycle(u, fs[i], 1.0, 2, 2, 1, 3, history=True))
+        plan.close()
+    import threading
+    plans = [make(i) for i in range(2)]
+    us = [torch.zeros_like(f) for f in fs]
+    torch.cuda.synchronize()
+    out = [None, None]
+
+    def work(i):
+        for _ in range(4):  # several rounds so that the two threads do overlap
+            us[i].zero_()
+            torch.cuda.current_stream().synchronize()
+            out[i] = plans[i].vcycle(us[i], fs[i], 1.0, 2, 2, 1, 3, history=True)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for p in plans:
+        p.close()
+    assert out[0] == serial[0] and out[1] == serial[1]
 
 
 def test_slab_rows_match_whole_grid(dev):

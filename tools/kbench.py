@@ -59,7 +59,6 @@ def main():
     timeit("residual", lambda: L.residual(g, r, u, f), 3 * N * w)
     n2 = torch.zeros(1, device="cuda", dtype=torch.float64)
     timeit("residual+norm", lambda: L.residual(g, r, u, f, norm2=n2), 3 * N * w)
-    timeit("residual_restrict", lambda: L.residual_restrict(g, gc, rc, u, f), (2 * N + Nc) * w)
     timeit("restrict", lambda: L.restrict(g, gc, rc, r), (N + Nc) * w)
     timeit("correct (in place)", lambda: L.correct(g, gc, u, u, e), (2 * N + Nc) * w)
     try:
