@@ -182,6 +182,18 @@ MGRT_DECLARE_KERNELS(float, _f32)
 MGRT_DECLARE_KERNELS(double, _f64)
 
 /*
+ * mgrt_sumsq_f32 for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments
+ * and result as mgrt_sumsq_f32 (the sum may differ in the last bits: the partial sums are grouped
+ * differently on large grids), but the block partials live in a fixed 512 KiB array inside the
+ * library instead of allocated scratch, and no allocating call is made.  Limit: nx * (yhi - ylo) at
+ * most 65536 * 256 = 16 777 216 points per plane (MGRT_E_INVALID beyond).  All calls on one GPU share
+ * the array: calls that overlap in time on one GPU (different streams) race; order them.
+ */
+mgrt_status mgrt_sumsq_noalloc_f32(const mgrt_grid *g, const float *x, double *out, int ylo, int yhi,
+                                   mgrt_stream s);
+
+/*
  * Pre-planned V-cycle: the level hierarchy of MultigridSolver{2,3}D::iterate
  * (multigridsolver3D.cpp:41-80: extents n -> (n+1)/2 while every extent > 3) with all work
  * arrays allocated once, where the reference allocates three buffers per level per call

@@ -45,7 +45,7 @@ _KERNELS = ["smooth_pass", "smooth", "smooth_sweep", "smooth_sweep_residual", "s
 _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "upload", "download",
             "stream_create", "stream_destroy", "sync", "zero", "box_cells_host",
             "plan_create", "plan_destroy", "plan_levels", "plan_level_dims", "plan_set_cells",
-            "plan_vcycle", "plan_fmg", "correct_smooth_sweep_supported"]
+            "plan_vcycle", "plan_fmg", "correct_smooth_sweep_supported", "sumsq_noalloc_f32"]
 SYMBOLS = ["mgrt_" + n for n in _RUNTIME] + ["mgrt_%s_%s" % (k, s) for k in _KERNELS for s in ("f32", "f64")]
 
 _lib = None
@@ -75,6 +75,7 @@ def load():
         "plan_set_cells": [p, i, p],
         "plan_vcycle": [p, p, p, d, i, i, i, i, C.POINTER(d)],
         "plan_fmg": [p, p, p, d, i, i, i, i],
+        "sumsq_noalloc_f32": [G, p, p, i, i, p],
     }
     for name, args in sig.items():
         f = getattr(lib, "mgrt_" + name)
@@ -235,6 +236,11 @@ def diff(g, out, a, b, stream=None):
 
 def sumsq(g, x, out, ylo=0, yhi=None, stream=None):
     check(_fn("sumsq", x)(C.byref(g), _p(x), _p(out), ylo, g.ny if yhi is None else yhi, _stream(stream)))
+
+
+def sumsq_noalloc(g, x, out, ylo=0, yhi=None, stream=None):
+    """mgrt_sumsq_noalloc_f32: sumsq with its scratch in a fixed array of the library (float only)."""
+    check(load().mgrt_sumsq_noalloc_f32(C.byref(g), _p(x), _p(out), ylo, g.ny if yhi is None else yhi, _stream(stream)))
 
 
 def maxabs(g, x, out, ylo=0, yhi=None, stream=None):

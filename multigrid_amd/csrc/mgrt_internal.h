@@ -30,6 +30,7 @@ struct Runtime {
     bool ready = false;
     int device = -1;
     int num_cu = 0;
+    double *static_partials = nullptr; // device address of the fixed scratch array of mgrt_sumsq_noalloc_f32
 };
 Runtime &runtime();
 mgrt_status require_init();
@@ -70,6 +71,12 @@ mgrt_status bottom_cycle(int dim, int nlev, const int *nx, const int *ny, const 
 mgrt_status bottom_cycle(int dim, int nlev, const int *nx, const int *ny, const int *nz, const int face[6], int zfull,
                          double *u, const double *u_in, const double *f, double omega, int a1, int a2, int v,
                          hipStream_t hs);
+
+// Entries of the fixed device array behind mgrt_sumsq_noalloc_f32 (512 KiB per GPU, held until the
+// process ends), and the set-up step that looks up its device address (mgrt_kernels.hip; called by
+// mgrt_init with the device current).
+constexpr int kStaticPartials = 1 << 16;
+mgrt_status static_partials_setup(double **device_address);
 
 // The fused 3D sweeps address a z plane with 32-bit byte offsets and use offset 2^31 as the one the
 // hardware range check always drops, so a plane (rows x pitch) must stay below 2 GiB.

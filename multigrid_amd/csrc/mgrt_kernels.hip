@@ -12,6 +12,20 @@
 
 using namespace mgrt;
 
+// Block partials of mgrt_sumsq_noalloc_f32, the one entry point that allocates nothing: a fixed array
+// in the code object instead of memory from hipMalloc.  Host code must not pass this name to a kernel
+// (on the host it is a stand-in, not a device address): static_partials_setup() asks the runtime for
+// the address once, with the device current, and everything uses that pointer.
+static __device__ __align__(256) double scratch[mgrt::kStaticPartials];
+
+namespace mgrt {
+mgrt_status static_partials_setup(double **device_address)
+{
+    MGRT_HIP(hipGetSymbolAddress((void **)device_address, HIP_SYMBOL(scratch)));
+    return MGRT_OK;
+}
+} // namespace mgrt
+
 namespace {
 
 constexpr int kWave = 64;
@@ -869,6 +883,39 @@ mgrt_status norm(const mgrt_grid *g, const R *x, double *out, int ylo, int yhi, 
     return fold<MAX>(parts, (int)(grid.x * grid.y), out, hs);
 }
 
+// mgrt_sumsq for callers that cannot allocate: the same two kernels, the block partials in the fixed
+// device array above.  No hipMalloc, hipFree or other allocating call on this path.
+mgrt_status sumsq_noalloc(const mgrt_grid *g, const float *x, double *out, int ylo, int yhi, mgrt_stream s)
+{
+    const char *who = "mgrt_sumsq_noalloc_f32";
+    if (mgrt_status st = require_init()) return st;
+    if (mgrt_status st = check_grid(g, who)) return st;
+    MGRT_REQUIRE(x && out, "%s: null pointer", who);
+    MGRT_REQUIRE(0 <= ylo && ylo <= yhi && yhi <= g->ny, "%s: rows [%d,%d) outside [0,%d)", who, ylo, yhi, g->ny);
+    double *parts = runtime().static_partials;
+    MGRT_REQUIRE(parts != nullptr, "%s: the scratch array was not set up", who);
+    hipStream_t hs = (hipStream_t)s;
+    const long long n = (long long)g->nx * (yhi - ylo);
+    if (n == 0) {
+        MGRT_HIP(hipMemsetAsync(out, 0, sizeof(double), hs));
+        return MGRT_OK;
+    }
+    const unsigned gx = blocks_for(n, 256);
+    // one partial per block: the rows times columns of one plane alone must fit the array, deeper z
+    // chunks take care of the planes
+    if ((long long)gx > (long long)kStaticPartials)
+        return fail(MGRT_E_INVALID, "%s: %lld points per plane need %u block partials, the fixed scratch array holds %d "
+                                    "(at most %lld points per plane); use mgrt_sumsq_f32",
+                    who, n, gx, kStaticPartials, (long long)kStaticPartials * 256);
+    int zc = 16;
+    while ((long long)gx * blocks_for(g->nz, zc) > (long long)kStaticPartials)
+        zc *= 2;
+    dim3 grid(gx, blocks_for(g->nz, zc));
+    k_norm_partials<float, false><<<grid, 256, 0, hs>>>(*g, x, parts, ylo, yhi, zc);
+    MGRT_HIP(hipGetLastError());
+    return fold<false>(parts, (int)(grid.x * grid.y), out, hs);
+}
+
 // Blocking: allocates the tree's intermediate arrays like the reference does (auxiliary.cpp:124).
 // MODE 0: L2 norm (square, sum, sqrt); 1: L-infinity norm; 2: plain sum (Average, auxiliary.h:84-94).
 template <class R, int MODE> mgrt_status reftree(const R *x, long long n, R *result, mgrt_stream s)
@@ -963,3 +1010,9 @@ template <class R, int MODE> mgrt_status reftree(const R *x, long long n, R *res
 
 MGRT_DEFINE_KERNELS(float, _f32)
 MGRT_DEFINE_KERNELS(double, _f64)
+
+extern "C" mgrt_status mgrt_sumsq_noalloc_f32(const mgrt_grid *g, const float *x, double *out, int ylo, int yhi,
+                                              mgrt_stream s)
+{
+    return sumsq_noalloc(g, x, out, ylo, yhi, s);
+}

@@ -117,6 +117,8 @@ mgrt_status mgrt_init(int device)
         return fail(MGRT_E_NO_DEVICE, "device %d is %s; this library holds gfx950 code only", device,
                     prop.gcnArchName);
     rt.num_cu = prop.multiProcessorCount;
+    if (mgrt_status st = static_partials_setup(&rt.static_partials))
+        return st;
     rt.device = device;
     rt.ready = true;
     return MGRT_OK;
