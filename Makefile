@@ -24,6 +24,10 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/mgrt_internal.h $(CSRC)/mgrt_device.h include
 $(LIB): $(LIB_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(LIB_OBJS)
 
+# diagnostic build with in-kernel time stamps in the fused sweep (tools/stamps.py); not the product
+stamps:
+	$(HIPCC) $(HIPFLAGS) -DMGRT_STAMPS -shared -o multigrid_amd/libmgrt_stamps.so $(LIB_SRCS)
+
 oracle:
 	$(MAKE) -C oracle
 
@@ -37,4 +41,4 @@ clean:
 	rm -f $(LIB_OBJS) $(LIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle ref host clean
+.PHONY: all lib stamps oracle ref host clean

@@ -40,6 +40,22 @@ namespace {
 
 constexpr int kWave = 64;
 
+// Diagnostic build only (-DMGRT_STAMPS, tools/stamps.py): shader-clock time a wavefront spends in each
+// segment of a fast time step, summed over the march, for the wavefronts of the middle block.
+#ifdef MGRT_STAMPS
+__device__ unsigned long long mgrt_stamps[16][8];
+#define MGRT_STAMP_BEGIN() (tprev = __builtin_amdgcn_s_memtime())
+#define MGRT_STAMP(k)                                                                              \
+    do {                                                                                           \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                \
+        acc[k] += t_ - tprev;                                                                      \
+        tprev = t_;                                                                                \
+    } while (0)
+#else
+#define MGRT_STAMP_BEGIN()
+#define MGRT_STAMP(k)
+#endif
+
 //
 // RES adds one more pass, two planes behind the last colour pass, where every neighbour is final:
 // res = f - A out on inner points, f - out on Dirichlet points, 0 elsewhere (residual_kernel,
@@ -65,16 +81,25 @@ template <class R> __device__ __forceinline__ R dot4(R a0, R a1, R a2, R a3, R b
     return a0 * b0 + a1 * b1 + a2 * b2 + a3 * b3;
 }
 
-template <class R, int ITERS, int SR, int NW, int PD, bool OMEGA1, bool RES, bool COR = false>
-__global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const R *__restrict__ in,
+//
+// STAGES = 2 splits the march between two groups of NW wavefronts that own the same strips: the first
+// group performs the first ITERS iterations and hands every finished plane (and its right-hand side)
+// to the second group through LDS instead of memory, which performs ITERS more and stores.  A
+// wavefront then issues half the instructions per time step; on levels whose sweep time is the
+// latency of a step rather than bandwidth that is what counts.  The second group runs
+// LAG = 2*ITERS + 1 steps behind the first; both share the one barrier per step.
+template <class R, int ITERS, int SR, int NW, int PD, bool OMEGA1, bool RES, bool COR = false, int STAGES = 1>
+__global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid g, const R *__restrict__ in,
                                                               R *__restrict__ out, const R *__restrict__ f,
                                                               R *__restrict__ res, R omega, int zcount, int ntx,
                                                               CoarseField cf)
 {
     static_assert(SR % 2 == 0, "rows are handled in pairs");
     static_assert(!COR || (PD == 2 && !RES), "the corrected input is built for a prefetch depth of two planes");
-    constexpr int NP = 2 * ITERS, J = SR / 2;
-    constexpr int H = NP + (RES ? 1 : 0);  // halo rings consumed
+    static_assert(STAGES == 1 || (STAGES == 2 && !RES && !COR), "stages hand on whole smoothed planes only");
+    constexpr int NP = 2 * ITERS, J = SR / 2;    // colour passes per stage
+    constexpr int H = NP * STAGES + (RES ? 1 : 0); // halo rings consumed by all stages together
+    constexpr int LAG = NP + 1;                  // steps between a plane leaving one stage and entering the next
     constexpr int DR = NP + 2;             // ring depth of the residual pass
     constexpr int ND = RES ? NP + 4 : NP + 2, NSET = RES ? NP + 2 : NP;
     // The plane rings (period ND) and the prefetch ring (period PD) are addressed with indices that
@@ -82,13 +107,16 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
     // i lives in ring slot i % ND and prefetch slot i % PD, nothing is ever shifted.
     static_assert(ND % PD == 0 || PD % ND == 0, "prefetch depth and ring depth must divide the unrolled loop");
     constexpr int UN = ND > PD ? ND : PD;
-    constexpr int kStores = RES ? 2 * SR : SR;                    // per step
-    constexpr int kYounger = kStores + (PD - 1) * (2 * SR + kStores); // see wait_slot
-    static_assert(kYounger < 64, "too many vector-memory operations in flight for a counted wait");
     constexpr int OX = kWave - 2 * H, OY = NW * SR - 2 * H;
-    __shared__ R bnd[2][NSET][NW][2][kWave];
+    __shared__ R bnd[2][NSET][NW * STAGES][2][kWave];
+    // hand-over between the stages: [step parity][strip][u | f][colour][row pair][lane]; a wavefront of
+    // the second stage reads exactly what the wavefront of the first stage with the same strip wrote
+    __shared__ R hand[2][STAGES > 1 ? NW : 1][2][2][J][kWave];
 
-    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    // wave-uniform by construction; read as a scalar so that the stages branch without exec masks
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);
+    const int stage = STAGES > 1 ? wave / NW : 0, w = STAGES > 1 ? wave % NW : wave;
     // Blocks are dealt to the 8 XCDs round-robin (block b and b+8 share an L2).  Give every XCD a
     // contiguous run of tiles, so that the halo columns and the partial cache lines two
     // neighbouring tiles both touch are fetched from HBM once and hit in that XCD's L2 the second
@@ -142,6 +170,22 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
         latfix[1][j] = latdir[1][j] && !interior[1][j];
     }
 
+    const long long slab = g.slab;
+    const int zlast = g.nz - 1;
+    const int zlim = zcount < g.nz ? zcount : g.nz;
+    const int wu = w > 0 ? w - 1 : 0, wd = w + 1 < NW ? w + 1 : NW - 1;
+
+    auto march = [&](auto stage_tag) {
+    constexpr int STG = decltype(stage_tag)::value;
+    constexpr bool FIRST = STG == 0, LAST = STG == STAGES - 1; // FIRST loads from memory, LAST stores to it
+    constexpr int lag = STG * LAG;
+    constexpr int WB = STG * NW; // this stage's wavefronts in bnd
+    constexpr int kStores = LAST ? (RES ? 2 * SR : SR) : 0;            // per step
+    constexpr int kYounger = kStores + (PD - 1) * (2 * SR + kStores); // see wait_slot
+    static_assert(kYounger < 64, "too many vector-memory operations in flight for a counted wait");
+#ifdef MGRT_STAMPS
+    unsigned long long acc[8] = {}, tprev = 0;
+#endif
     R C[2][ND][J], F[2][ND][J];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -149,9 +193,6 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
         for (int d = 0; d < ND; ++d)
 #pragma unroll
             for (int j = 0; j < J; ++j) C[c][d][j] = F[c][d][j] = 0;
-
-    const long long slab = g.slab;
-    const int zlast = g.nz - 1;
 
     // ---- coarse-grid correction: offsets, weights, the two coarse planes in registers ----------
     constexpr int NCR = SR / 2 + 1; // coarse rows under SR fine rows that start on an even row
@@ -194,34 +235,40 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
         }
     };
     R pu[PD][SR], pf[PD][SR];
+    if constexpr (FIRST) {
 #pragma unroll
-    for (int k = 0; k < PD; ++k) {
-        const long long zo = slab * (k < zlast ? k : zlast);
-        const desc_t ru = plane_desc(inb + zo, in_bytes), rf = plane_desc(f + zo, plane_bytes);
+        for (int k = 0; k < PD; ++k) {
+            const long long zo = slab * (k < zlast ? k : zlast);
+            const desc_t ru = plane_desc(inb + zo, in_bytes), rf = plane_desc(f + zo, plane_bytes);
 #pragma unroll
-        for (int r = 0; r < SR; ++r) {
-            buf_load_hidden(pu[k][r], ru, off[r]);
-            buf_load_hidden(pf[k][r], rf, off[r]);
+            for (int r = 0; r < SR; ++r) {
+                buf_load_hidden(pu[k][r], ru, off[r]);
+                buf_load_hidden(pf[k][r], rf, off[r]);
+            }
         }
     }
     auto drain0 = [&]() {
+        if constexpr (FIRST) {
 #pragma unroll
-        for (int k = 0; k < PD; ++k)
-            wait_slot<0>(pu[k], pf[k]);
+            for (int k = 0; k < PD; ++k)
+                wait_slot<0>(pu[k], pf[k]);
+        }
         pin_coarse(pe);
         pin_coarse(Eb);
     };
     drain0(); // the loop below starts from landed registers (see `drain`)
 
-    const int nsteps = g.nz + (RES ? DR : NP); // planes entering the ring: the last one finishes plane nz-1
-    const int zlim = zcount < g.nz ? zcount : g.nz;
-    const int wu = w > 0 ? w - 1 : 0, wd = w + 1 < NW ? w + 1 : NW - 1;
+    // planes entering this stage's ring: the last one finishes plane nz-1; all stages together take
+    // nsteps_all time steps, every one of them with a barrier that every wavefront of the block joins
+    const int nsteps = g.nz + (RES ? DR : NP);
+    const int nsteps_all = nsteps + (STAGES - 1) * LAG;
     // One group of UN consecutive time steps, unrolled so that every ring index is a constant.
     // FAST groups are those whose steps all work on planes strictly between the z faces and below
     // zlim, prefetch planes that exist, and store a plane: no per-step conditions are left and the
     // class of a point is a per-lane constant.
-    auto group = [&](auto fast_tag, const int i0) {
+    auto group = [&](auto fast_tag, const int g0) { // g0: first time step of the group, counted for the block
         constexpr bool FAST = decltype(fast_tag)::value;
+        const int i0 = g0 - lag; // the same, counted for this stage: plane i0 enters its ring
         // Plane addresses of a fast group advance by one slab per step: keep running pointers
         // (two scalar adds each) instead of a 64-bit multiply per array and step.
         // The descriptors themselves are the running state: base address in words 0 and 1.
@@ -238,8 +285,8 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
         };
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int i = i0 + u; // plane entering the ring; i0 is a multiple of UN
-            if (FAST || i < nsteps) {
+            const int i = i0 + u; // plane entering the ring; g0 is a multiple of UN
+            if (FAST || g0 + u < nsteps_all) {
 #define PH(d) ((((u) - (d)) % ND + ND) % ND) /* ring slot of depth d, i.e. of plane i - d */
                 const int ps = u % PD; // prefetch slot of plane i (a constant once the loop is unrolled)
                 // ---- plane i: prefetch registers -> ring slot -----------------------------------
@@ -248,14 +295,22 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                 // skip their stores, so wait for everything.
                 // With COR the slots of even planes carry the 2*NCR coarse loads as well, so an odd
                 // plane's slot has that many more operations behind it.
+                if (FAST) {
+                    MGRT_STAMP_BEGIN();
+                }
                 constexpr int kYoungerOdd = kYounger + (COR ? 2 * NCR : 0);
                 static_assert(!COR || kYoungerOdd + 2 * SR + 2 * NCR < 64, "too many vector-memory operations in flight");
-                if (!FAST)
-                    wait_slot<0>(pu[ps], pf[ps]);
-                else if (u & 1) // folds once the loop is unrolled
-                    wait_slot<kYoungerOdd>(pu[ps], pf[ps]);
-                else
-                    wait_slot<kYounger>(pu[ps], pf[ps]);
+                if constexpr (FIRST) {
+                    if (!FAST)
+                        wait_slot<0>(pu[ps], pf[ps]);
+                    else if (u & 1) // folds once the loop is unrolled
+                        wait_slot<kYoungerOdd>(pu[ps], pf[ps]);
+                    else
+                        wait_slot<kYounger>(pu[ps], pf[ps]);
+                }
+                if (FAST) {
+                    MGRT_STAMP(0); // waiting for the prefetched plane
+                }
                 R cor[SR];
                 if constexpr (COR) {
                     const int pz = u & 1; // parity of plane i
@@ -288,6 +343,7 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                         cor[r] = (border ? Ea[m][0] : val) * 4;
                     }
                 }
+                if constexpr (FIRST) {
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
                     const R a0 = COR ? pu[ps][2 * j] + cor[COR ? 2 * j : 0] : pu[ps][2 * j];
@@ -303,7 +359,8 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                     // ahead of the wait.
                     asm volatile("" : "+v"(C[0][PH(0)][j]), "+v"(C[1][PH(0)][j]), "+v"(F[0][PH(0)][j]), "+v"(F[1][PH(0)][j]));
                 }
-                { // plane i + PD -> prefetch slot ps
+                }
+                if constexpr (FIRST) { // plane i + PD -> prefetch slot ps
                     const int zn = i + PD;
                     const long long zo = slab * (zn < zlast ? zn : zlast);
                     const desc_t ru = FAST ? d_in : plane_desc(inb + zo, in_bytes);
@@ -332,17 +389,34 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
 #pragma unroll
                 for (int d = 1; d <= NP; ++d) {
                     const int oc = ((d - 1) & 1) ^ 1;
-                    bnd[par][d - 1][w][0][lane] = C[oc][PH(d)][0];
-                    bnd[par][d - 1][w][1][lane] = C[oc][PH(d)][J - 1];
+                    bnd[par][d - 1][WB + w][0][lane] = C[oc][PH(d)][0];
+                    bnd[par][d - 1][WB + w][1][lane] = C[oc][PH(d)][J - 1];
                 }
                 if (RES) {
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        bnd[par][NSET - 2 + c][w][0][lane] = C[c][PH(DR)][0];
-                        bnd[par][NSET - 2 + c][w][1][lane] = C[c][PH(DR)][J - 1];
+                        bnd[par][NSET - 2 + c][WB + w][0][lane] = C[c][PH(DR)][0];
+                        bnd[par][NSET - 2 + c][WB + w][1][lane] = C[c][PH(DR)][J - 1];
                     }
                 }
+                if (FAST) {
+                    MGRT_STAMP(1); // ring insert, requests for the next plane, publishing the edge rows
+                }
                 __syncthreads();
+                if (FAST) {
+                    MGRT_STAMP(2); // the barrier
+                }
+                if constexpr (!FIRST) {
+                    // plane i as the stage before left it at the end of the previous step, already
+                    // split by colour (same strip, same lanes: same row parity)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int j = 0; j < J; ++j) {
+                            C[c][PH(0)][j] = hand[par ^ 1][w][0][c][j][lane];
+                            F[c][PH(0)][j] = hand[par ^ 1][w][1][c][j][lane];
+                        }
+                }
                 // ---- the passes: pass d = colour (d-1)%2 of iteration (d+1)/2 on plane i - d ----
 #pragma unroll
                 for (int d = 1; d <= NP; ++d) {
@@ -350,8 +424,8 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                     const bool sc = (s0 ^ c) != 0; // odd row of the pair holds the colour-c point
                     const int z = i - d;
                     if (FAST || (z >= 0 && z < zlim)) {
-                        const R up = bnd[par][d - 1][wu][1][lane];
-                        const R dn = bnd[par][d - 1][wd][0][lane];
+                        const R up = bnd[par][d - 1][WB + wu][1][lane];
+                        const R dn = bnd[par][d - 1][WB + wd][0][lane];
                         const int zcls = z == 0 ? g.face[4] : (z == zlast ? g.face[5] : MGRT_CELL_INNER);
                         const bool zin = zcls == MGRT_CELL_INNER, zdir = zcls == MGRT_CELL_DIRICHLET;
 #pragma unroll
@@ -368,7 +442,8 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                             // double literal 1.0/6.0, rounded to R
                             const R val = (1.0 / 6.0) * (xp + xm + yp + ym + C[c][PH(d - 1)][j] + C[c][PH(d + 1)][j] - fv);
                             // mg_1.cl:69; for omega == 1 the double expression reduces exactly
-                            // to val + 0*own evaluated in R
+                            // to val + 0*own evaluated in R (one fused multiply-add would give the
+                            // same bits, the product being exact, but measured 5 % slower per cycle)
                             R gs = OMEGA1 ? val + (R)0 * own : (R)(val * omega + (1.0 - omega) * own);
                             // Keep the update unconditional: left alone, the compiler sinks it
                             // under a branch on take_gs, and the exec-mask blocks that result
@@ -380,9 +455,21 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                         }
                     }
                 }
+                if (FAST) {
+                    MGRT_STAMP(3); // neighbour rows from LDS and the colour passes
+                }
                 // ---- plane i - NP is final: store the tile's interior ----------------------------
                 const int zf = i - NP;
-                if (FAST || (zf >= 0 && zf <= zlast)) {
+                if constexpr (!LAST) {
+                    // on to the next stage, which takes it up after the next barrier
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int j = 0; j < J; ++j) {
+                            hand[par][w][0][c][j][lane] = C[c][PH(NP)][j];
+                            hand[par][w][1][c][j][lane] = F[c][PH(NP)][j];
+                        }
+                } else if (FAST || (zf >= 0 && zf <= zlast)) {
                     const desc_t ro = FAST ? d_out : plane_desc(out + slab * zf, plane_bytes);
 #pragma unroll
                     for (int r = 0; r < SR; ++r)
@@ -399,8 +486,8 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                         for (int c = 0; c < 2; ++c) {
                             const bool sc = (s0 ^ c) != 0;
                             // first / last row of the other colour in the neighbouring strips
-                            const R up = bnd[par][NSET - 2 + (c ^ 1)][wu][1][lane];
-                            const R dn = bnd[par][NSET - 2 + (c ^ 1)][wd][0][lane];
+                            const R up = bnd[par][NSET - 2 + (c ^ 1)][WB + wu][1][lane];
+                            const R dn = bnd[par][NSET - 2 + (c ^ 1)][WB + wd][0][lane];
 #pragma unroll
                             for (int j = 0; j < J; ++j) {
                                 const R o = C[c ^ 1][PH(DR)][j];
@@ -426,6 +513,12 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
                 }
 #undef PH
                 if (FAST) {
+                    MGRT_STAMP(4); // stores / hand-over (and the residual pass)
+#ifdef MGRT_STAMPS
+                    acc[7] += 1;
+#endif
+                }
+                if (FAST && (FIRST || LAST)) {
                     advance(d_in, slab_bytes), advance(d_f, slab_bytes), advance(d_out, slab_bytes);
                     if (RES)
                         advance(d_res, slab_bytes);
@@ -441,9 +534,11 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
     // copies); everywhere else the compiler may copy loop-carried registers at a loop latch, so
     // every other path drains all prefetches before it reaches one.
     auto drain = [&]() {
+        if constexpr (FIRST) {
 #pragma unroll
-        for (int k = 0; k < PD; ++k)
-            wait_slot<0>(pu[k], pf[k]);
+            for (int k = 0; k < PD; ++k)
+                wait_slot<0>(pu[k], pf[k]);
+        }
         pin_coarse(pe);
     };
     // first step of a group: deepest plane (i0 - NP, or i0 - DR with the residual pass) >= 1; last
@@ -457,27 +552,45 @@ __global__ __launch_bounds__(NW *kWave) void k_smooth3d_fused(mgrt_grid g, const
     // register allocator keeps every ring and prefetch register in place across the back edge
     // (a shared loop made it copy the freshly requested prefetch registers at the latch, which
     // forces a full vmcnt(0) drain per group).
-    for (int i0 = 0; i0 < nsteps;) {
-        if (is_fast(i0)) {
+    // Every wavefront of the block walks the same sequence of groups (one barrier per time step each);
+    // whether a group is a fast one is each stage's own matter.
+    for (int g0 = 0; g0 < nsteps_all;) {
+        if (is_fast(g0 - lag)) {
             do {
-                group(std::true_type{}, i0);
-                i0 += UN;
-            } while (is_fast(i0));
+                group(std::true_type{}, g0);
+                g0 += UN;
+            } while (is_fast(g0 - lag));
             drain();
         } else {
-            group(std::false_type{}, i0);
-            i0 += UN;
+            group(std::false_type{}, g0);
+            g0 += UN;
             drain();
         }
     }
+#ifdef MGRT_STAMPS
+    if (blockIdx.x == gridDim.x / 2 && lane == 0)
+        for (int k = 0; k < 8; ++k)
+            mgrt_stamps[wave & 15][k] = acc[k];
+#endif
+    }; // march
+
+    if constexpr (STAGES == 1) {
+        march(std::integral_constant<int, 0>{});
+    } else {
+        if (stage == 0)
+            march(std::integral_constant<int, 0>{});
+        else
+            march(std::integral_constant<int, 1>{});
+    }
 }
 
-template <class R, int ITERS, int SR, int NW, int PD, bool RES = false, bool COR = false>
+template <class R, int ITERS, int SR, int NW, int PD, bool RES = false, bool COR = false, int STAGES = 1>
 mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, int zcount, hipStream_t hs,
                    R *res = nullptr, const mgrt_grid *cg = nullptr, const R *e = nullptr)
 {
-    constexpr int H = 2 * ITERS + (RES ? 1 : 0), OX = kWave - 2 * H, OY = NW * SR - 2 * H;
+    constexpr int H = 2 * ITERS * STAGES + (RES ? 1 : 0), OX = kWave - 2 * H, OY = NW * SR - 2 * H;
     static_assert(OY > 0, "tile has no interior");
+    static_assert(NW * STAGES * kWave <= 1024, "block too large");
     // every strip starts on an even row of its slab (the corrected input relies on it)
     static_assert(!COR || (OY % 2 == 0 && H % 2 == 0), "strips must start on even rows");
     const int ntx = (g->nx + OX - 1) / OX, nty = (g->ny + OY - 1) / OY;
@@ -488,9 +601,9 @@ mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega,
         cf.nx = cg->nx, cf.ny = cg->ny, cf.nz = cg->nz, cf.y0 = cg->y0;
     }
     if (omega == (R)1)
-        k_smooth3d_fused<R, ITERS, SR, NW, PD, true, RES, COR><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
+        k_smooth3d_fused<R, ITERS, SR, NW, PD, true, RES, COR, STAGES><<<grid, NW * STAGES * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
     else
-        k_smooth3d_fused<R, ITERS, SR, NW, PD, false, RES, COR><<<grid, NW * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
+        k_smooth3d_fused<R, ITERS, SR, NW, PD, false, RES, COR, STAGES><<<grid, NW * STAGES * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
     MGRT_HIP(hipGetLastError());
     return MGRT_OK;
 }
@@ -499,12 +612,10 @@ template <class R> struct Cfg;
 template <> struct Cfg<float> {
     static constexpr int SR1 = 4, NW1 = 8, PF1 = 4; // one iteration per sweep: 4 planes prefetched
     static constexpr int SR2 = 4, NW2 = 8, PF2 = 2; // two iterations per sweep: 2 planes prefetched
-    static constexpr int NWS2 = 8, PFS2 = 3;        // waves per block and prefetch depth of the small-level shape
 };
 template <> struct Cfg<double> {
     static constexpr int SR1 = 4, NW1 = 4, PF1 = 4;
     static constexpr int SR2 = 4, NW2 = 8, PF2 = 2; // 238-246 registers: one block of 8 waves per CU
-    static constexpr int NWS2 = 12, PFS2 = 3;
 };
 
 // res == nullptr: the sweep alone; otherwise the sweep with the residual pass.
@@ -543,7 +654,12 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
     if (iters == 1)
         return small ? launch<R, 1, 2, 8, 4>(g, out, in, f, omega, zcount, hs)
                      : launch<R, 1, C::SR1, C::NW1, C::PF1>(g, out, in, f, omega, zcount, hs);
-    return small ? launch<R, 2, 2, C::NWS2, C::PFS2>(g, out, in, f, omega, zcount, hs)
+    // Latency-bound levels: strips of two rows.  From about 100^2 columns up as two stages of one
+    // iteration each (16 wavefronts a block; measured 105 vs 114 us at 257^3, 54 vs 59 at 129^3), below
+    // that as one stage (20 vs 23 us at 33^3: few blocks, and the second stage only adds its lag).
+    if (small && (long long)g->nx * g->ny >= 100LL * 100LL)
+        return launch<R, 1, 2, 8, 4, false, false, 2>(g, out, in, f, omega, zcount, hs);
+    return small ? launch<R, 2, 2, sizeof(R) == 4 ? 8 : 12, 3>(g, out, in, f, omega, zcount, hs)
                  : launch<R, 2, C::SR2, C::NW2, C::PF2>(g, out, in, f, omega, zcount, hs);
 }
 
@@ -615,6 +731,15 @@ mgrt_status smooth_sweep_residual_restrict(const mgrt_grid *fine, const mgrt_gri
 }
 
 } // namespace
+
+#ifdef MGRT_STAMPS
+extern "C" mgrt_status mgrt_debug_stamps(unsigned long long *out)
+{
+    MGRT_HIP(hipDeviceSynchronize());
+    MGRT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(mgrt_stamps), sizeof(unsigned long long) * 16 * 8));
+    return MGRT_OK;
+}
+#endif
 
 extern "C" mgrt_status mgrt_smooth_sweep_residual_restrict_f32(const mgrt_grid *fine, const mgrt_grid *coarse, float *out,
                                                                float *rc, const float *in, const float *f, float omega,
