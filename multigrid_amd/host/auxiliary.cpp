@@ -92,6 +92,55 @@ Buffer3D Difference(const Buffer3D &a, const Buffer3D &b, Stream &q)
 double ExactL2Norm(const Field &in, int depth, Stream &q) { return exact(in, depth, q, false); }
 double ExactLInfNorm(const Field &in, int depth, Stream &q) { return exact(in, depth, q, true); }
 
+// ---- work-group shape (auxiliary.cpp:33-117) --------------------------------------------------------
+namespace {
+
+const size_t kMaxItemsPerDim = 1024, kMaxGroup = 1024; // hipDeviceProp_t of gfx950
+
+// divisors of n that a dimension of a group may have, largest first
+std::vector<size_t> divisors(size_t n)
+{
+    std::vector<size_t> d;
+    for (size_t i = n; i >= 1; --i)
+        if (n % i == 0 && i <= kMaxItemsPerDim)
+            d.push_back(i);
+    return d;
+}
+
+// largest choice for dimension `k` that leaves the later dimensions a choice within `room`
+bool choose(const std::vector<std::vector<size_t> > &div, size_t k, size_t room, size_t *out)
+{
+    for (size_t i = 0; i < div[k].size(); ++i) {
+        const size_t v = div[k][i];
+        if (v > room)
+            continue;
+        if (k + 1 == div.size() || choose(div, k + 1, room / v, out)) {
+            out[k] = v;
+            return true;
+        }
+    }
+    return false;
+}
+
+} // namespace
+
+mgrt::NDRange getBestWorkspaceDim(mgrt::NDRange wsDim)
+{
+    const size_t nd = wsDim.dimensions();
+    if (nd == 0)
+        return mgrt::NullRange;
+    std::vector<std::vector<size_t> > div(nd);
+    for (size_t i = 0; i < nd; ++i) {
+        if (wsDim[i] == 0)
+            return mgrt::NullRange;
+        div[i] = divisors(wsDim[i]);
+    }
+    size_t dims[3] = {1, 1, 1};
+    if (!choose(div, 0, kMaxGroup, dims))
+        return mgrt::NullRange;
+    return nd == 1 ? mgrt::NDRange(dims[0]) : nd == 2 ? mgrt::NDRange(dims[0], dims[1]) : mgrt::NDRange(dims[0], dims[1], dims[2]);
+}
+
 // ---- 8-bit BMP (auxiliary.cpp:181-303) -----------------------------------------------------------
 // Layout written: 14-byte file header, 40-byte info header, 256-entry grey palette (4 bytes each),
 // rows padded to a multiple of 4 pixels, pixel = 255*|v|/max|v| truncated to a byte.

@@ -75,6 +75,24 @@ private:
     std::shared_ptr<Handle> m_s;
 };
 
+// Extents of a launch range in up to three dimensions: stands where the reference's interface names
+// cl::NDRange (auxiliary.h: getBestWorkspaceDim).  Converts to a pointer to its sizes, as that does.
+class NDRange
+{
+public:
+    NDRange() : m_dims(0) { m_size[0] = m_size[1] = m_size[2] = 0; }
+    NDRange(size_t s0) : m_dims(1) { m_size[0] = s0, m_size[1] = m_size[2] = 0; }
+    NDRange(size_t s0, size_t s1) : m_dims(2) { m_size[0] = s0, m_size[1] = s1, m_size[2] = 0; }
+    NDRange(size_t s0, size_t s1, size_t s2) : m_dims(3) { m_size[0] = s0, m_size[1] = s1, m_size[2] = s2; }
+    size_t dimensions() const { return m_dims; }
+    operator const size_t *() const { return m_size; }
+
+private:
+    size_t m_size[3];
+    size_t m_dims;
+};
+static const NDRange NullRange;
+
 // Where a BorderHandler binds its cell description for one launch: the handler fills in the box
 // face classes or the device pointer of a byte map (one MGRT_CELL_* value per grid point).
 struct KernelArgs {

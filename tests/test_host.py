@@ -35,6 +35,29 @@ def test_no_device_is_reported_not_worked_around():
     assert "No devices found" in p.stdout
 
 
+@pytest.mark.parametrize("extents, want", [
+    ((257, 513, 257), (257, 3, 1)),     # the 513^3 smoother range (multigridsolver3D.cpp:121): 257 is prime
+    ((513, 513, 513), (513, 1, 1)),
+    ((129, 257), (129, 1)),
+    ((64, 64, 64), (64, 16, 1)),
+    ((4097,), (241,)),                  # 4097 = 17 * 241
+    ((2053, 8), (1, 8)),                # a prime beyond the per-dimension limit
+])
+def test_get_best_workspace_dim(extents, want):
+    """getBestWorkspaceDim (auxiliary.cpp:33-117): largest divisors within 1024 per dimension, first
+    dimension first, product within 1024."""
+    exe = os.path.join(HOST, "workspace_dim")
+    assert os.access(exe, os.X_OK), "run `make host`"
+    out = subprocess.run([exe] + [str(e) for e in extents], capture_output=True, text=True, timeout=30)
+    got = tuple(int(t) for t in out.stdout.split())
+    assert got == want
+    prod = 1
+    for e, g in zip(extents, got):
+        assert e % g == 0
+        prod *= g
+    assert prod <= 1024
+
+
 def celltype(x, y, z, nx, ny, nz):
     threed = nz > 1
     if x == 0 or x == nx - 1:
