@@ -11,7 +11,7 @@ ARCH     ?= gfx950
 HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Iinclude -Wall -Wno-unused-function
 CSRC      = multigrid_amd/csrc
 LIB       = multigrid_amd/libmgrt.so
-LIB_SRCS  = $(CSRC)/mgrt_runtime.hip $(CSRC)/mgrt_kernels.hip $(CSRC)/mgrt_smooth_fused.hip $(CSRC)/mgrt_smooth2d.hip $(CSRC)/mgrt_bottom.hip $(CSRC)/mgrt_plan.hip
+LIB_SRCS  = $(CSRC)/mgrt_runtime.hip $(CSRC)/mgrt_kernels.hip $(CSRC)/mgrt_smooth_fused.hip $(CSRC)/mgrt_smooth2d.hip $(CSRC)/mgrt_bottom.hip $(CSRC)/mgrt_plan.hip $(CSRC)/mgrt_slab.hip
 LIB_OBJS  = $(LIB_SRCS:.hip=.o)
 
 all: lib oracle host
@@ -22,7 +22,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/mgrt_internal.h $(CSRC)/mgrt_device.h include
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 $(LIB): $(LIB_OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(LIB_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(LIB_OBJS) -ldl
 
 # diagnostic build with in-kernel time stamps in the fused sweep (tools/stamps.py); not the product
 stamps:

@@ -39,7 +39,8 @@ enum {
     MGRT_E_INVALID = -1,     /* bad argument (null pointer, extent, range, alignment) */
     MGRT_E_UNSUPPORTED = -2, /* valid request the library does not implement */
     MGRT_E_NOT_INIT = -3,    /* mgrt_init has not been called */
-    MGRT_E_NO_DEVICE = -4    /* no gfx950 device visible */
+    MGRT_E_NO_DEVICE = -4,   /* no gfx950 device visible */
+    MGRT_E_TRANSPORT = -5    /* RCCL or a transport callback reported a failure */
 };
 
 /* cell classes: the values of BorderHandler3D::CellType (multigridsolver3D.h:28), which stand
@@ -232,6 +233,70 @@ mgrt_status mgrt_plan_vcycle(mgrt_plan *plan, void *u, const void *f, double ome
 /* fmg(f, ...) of multigridsolver3D.cpp:82-109 into u_out (dense device array) */
 mgrt_status mgrt_plan_fmg(mgrt_plan *plan, void *u_out, const void *f, double omega, int a1,
                           int a2, int v, int iters);
+
+/*
+ * The same cycle with the grid cut into y-slabs, one slab per process and GPU.  The reference has one
+ * device and one in-order queue (clcontextloader.cpp:57, multigridsolver3D.cpp:36); this extends
+ * MultigridSolver3D::iterate (multigridsolver3D.cpp:41-80) to several GPUs with bitwise the results
+ * of one: the cut is along y only, so every z column, and the z recurrence of a colour pass with it,
+ * stays on one rank.  Rank r owns rows [B_r, B_r+1) of level 0, B_r a multiple of 2^(levels cut), and
+ * stores four halo rows of each neighbour; levels of at most `crossover` points are gathered and
+ * solved whole on every rank.  3D grids, analytic box.
+ *
+ * How halos travel is the transport's business:
+ *   MGRT_TRANSPORT_RCCL      ncclSend/ncclRecv with the two neighbours, ncclAllGather, ncclAllReduce on
+ *                            the plan's stream; with use_graph a whole cycle, communication included,
+ *                            is one hipGraph per rank.  librccl.so.1 is bound at run time.
+ *   MGRT_TRANSPORT_CALLBACK  blocking host functions that move device buffers (the stream is
+ *                            synchronised before each call); cycles are launched directly.
+ *   MGRT_TRANSPORT_NONE      nothing leaves the device: with nranks > 1 the plan is the share of one
+ *                            rank of a larger run with copies of the same size in place of the wire,
+ *                            for timing on one GPU (the values are not those of the whole problem).
+ */
+enum { MGRT_TRANSPORT_NONE = 0, MGRT_TRANSPORT_RCCL = 1, MGRT_TRANSPORT_CALLBACK = 2 };
+
+typedef struct mgrt_transport {
+    int kind;                   /* MGRT_TRANSPORT_* */
+    int rank, nranks;
+    unsigned char rccl_id[128]; /* RCCL: the ncclUniqueId of mgrt_rccl_unique_id() on one rank, the same on all */
+    /* CALLBACK: each returns 0 on success.  Pointers are device memory, sizes are bytes. */
+    void *ctx;
+    /* exchange with n peers at once: send[k] goes to peers[k], recv[k] comes from it */
+    int (*sendrecv)(void *ctx, int n, const int *peers, void *const *send, void *const *recv, const size_t *bytes);
+    /* recv holds nranks parts of `bytes` each, part r from rank r */
+    int (*allgather)(void *ctx, const void *send, void *recv, size_t bytes);
+    /* sum of one double over all ranks, in place */
+    int (*allreduce_sum)(void *ctx, double *value);
+} mgrt_transport;
+
+typedef struct mgrt_slab_desc {
+    int nx, ny, nz;      /* extents of the whole finest grid */
+    int elem_size;       /* 4 = float, 8 = double */
+    int face[6];
+    int zfull;           /* as mgrt_plan_desc */
+    int use_graph;       /* replay each distinct cycle from a captured hipGraph where the transport allows */
+    long long crossover; /* levels with at most this many points are not cut */
+} mgrt_slab_desc;
+
+typedef struct mgrt_slab_plan mgrt_slab_plan;
+
+/* a fresh ncclUniqueId (ncclGetUniqueId); one rank makes it, every rank passes it in mgrt_transport */
+mgrt_status mgrt_rccl_unique_id(unsigned char id[128]);
+/* collective over the transport's ranks; `s` must be a stream of its own (not NULL) */
+mgrt_status mgrt_slab_plan_create(mgrt_slab_plan **plan, const mgrt_slab_desc *desc, const mgrt_transport *transport,
+                                  mgrt_stream s);
+mgrt_status mgrt_slab_plan_destroy(mgrt_slab_plan *plan);
+/* number of levels cut into slabs (0: the grid is too small, or one rank: every rank holds all of it) */
+int mgrt_slab_plan_distributed_levels(const mgrt_slab_plan *plan);
+/* 1 while cycles are replayed from a graph (0 after a refused capture, or by choice of transport) */
+int mgrt_slab_plan_uses_graph(const mgrt_slab_plan *plan);
+/* this rank stores global rows [lo, hi) of level 0 and owns [own_lo, own_hi) */
+mgrt_status mgrt_slab_plan_rows(const mgrt_slab_plan *plan, int *lo, int *hi, int *own_lo, int *own_hi);
+/* `ncycles` times iterate(u, f, omega, a1, a2, v) on this rank's rows: u (in/out) and f are dense
+ * device arrays of nz x (hi - lo) x nx elements, halo rows included; those of f must be filled, those
+ * of u are exchanged here.  res_hist as in mgrt_plan_vcycle, norms over the whole grid. */
+mgrt_status mgrt_slab_plan_vcycle(mgrt_slab_plan *plan, void *u, const void *f, double omega, int a1, int a2, int v,
+                                  int ncycles, double *res_hist);
 
 #ifdef __cplusplus
 }

@@ -39,13 +39,38 @@ class PlanDesc(C.Structure):
     ]
 
 
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                          C.POINTER(C.c_size_t))
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+TRANSPORT_NONE, TRANSPORT_RCCL, TRANSPORT_CALLBACK = 0, 1, 2
+
+
+class Transport(C.Structure):
+    """mgrt_transport"""
+    _fields_ = [
+        ("kind", C.c_int), ("rank", C.c_int), ("nranks", C.c_int), ("rccl_id", C.c_ubyte * 128),
+        ("ctx", C.c_void_p), ("sendrecv", SENDRECV_FN), ("allgather", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN),
+    ]
+
+
+class SlabDesc(C.Structure):
+    """mgrt_slab_desc"""
+    _fields_ = [
+        ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("elem_size", C.c_int), ("face", C.c_int * 6),
+        ("zfull", C.c_int), ("use_graph", C.c_int), ("crossover", C.c_longlong),
+    ]
+
+
 # every symbol include/mgrt.h declares; checked by the CPU test-suite against the header
 _KERNELS = ["smooth_pass", "smooth", "smooth_sweep", "smooth_sweep_residual", "smooth_sweep_residual_restrict", "correct_smooth_sweep", "residual", "restrict", "correct", "prolong", "zero_outside",
             "diff", "sumsq", "maxabs", "l2norm_reftree", "linfnorm_reftree", "sum_reftree"]
 _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "upload", "download",
             "stream_create", "stream_destroy", "sync", "zero", "box_cells_host",
             "plan_create", "plan_destroy", "plan_levels", "plan_level_dims", "plan_set_cells",
-            "plan_vcycle", "plan_fmg", "correct_smooth_sweep_supported", "sumsq_noalloc_f32"]
+            "plan_vcycle", "plan_fmg", "correct_smooth_sweep_supported", "sumsq_noalloc_f32",
+            "rccl_unique_id", "slab_plan_create", "slab_plan_destroy", "slab_plan_distributed_levels",
+            "slab_plan_uses_graph", "slab_plan_rows", "slab_plan_vcycle"]
 SYMBOLS = ["mgrt_" + n for n in _RUNTIME] + ["mgrt_%s_%s" % (k, s) for k in _KERNELS for s in ("f32", "f64")]
 
 _lib = None
@@ -76,6 +101,11 @@ def load():
         "plan_vcycle": [p, p, p, d, i, i, i, i, C.POINTER(d)],
         "plan_fmg": [p, p, p, d, i, i, i, i],
         "sumsq_noalloc_f32": [G, p, p, i, i, p],
+        "rccl_unique_id": [p],
+        "slab_plan_create": [C.POINTER(p), C.POINTER(SlabDesc), C.POINTER(Transport), p],
+        "slab_plan_destroy": [p],
+        "slab_plan_rows": [p, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)],
+        "slab_plan_vcycle": [p, p, p, d, i, i, i, i, C.POINTER(d)],
     }
     for name, args in sig.items():
         f = getattr(lib, "mgrt_" + name)
@@ -83,6 +113,9 @@ def load():
         f.argtypes = args
     lib.mgrt_plan_levels.restype = i
     lib.mgrt_plan_levels.argtypes = [p]
+    for name in ("slab_plan_distributed_levels", "slab_plan_uses_graph"):
+        getattr(lib, "mgrt_" + name).restype = i
+        getattr(lib, "mgrt_" + name).argtypes = [p]
     lib.mgrt_correct_smooth_sweep_supported.restype = i
     lib.mgrt_correct_smooth_sweep_supported.argtypes = [G, i, i]
     for S, r in (("f32", C.c_float), ("f64", C.c_double)):
@@ -334,3 +367,154 @@ class Plan:
         assert u_out.is_contiguous() and f.is_contiguous()
         assert tuple(u_out.shape) == self.shape and tuple(f.shape) == self.shape
         check(load().mgrt_plan_fmg(self._h, _p(u_out), _p(f), omega, a1, a2, v, iters))
+
+
+def rccl_unique_id():
+    """128 bytes of a fresh ncclUniqueId (made on one rank, handed to all)."""
+    buf = (C.c_ubyte * 128)()
+    check(load().mgrt_rccl_unique_id(buf))
+    return bytes(buf)
+
+
+class GlooTransport:
+    """Blocking host callbacks over torch.distributed (any backend that moves CPU tensors): device
+    buffers are staged through host memory.  For tests and rehearsals on a box with fewer GPUs than
+    ranks; a measurement uses the RCCL transport."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.torch, self.group = dist, torch, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        lib = load()
+
+        def down(ptr, nbytes):
+            t = torch.empty(nbytes, dtype=torch.uint8)
+            check(lib.mgrt_download(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), nbytes, None))
+            return t
+
+        def up(ptr, t):
+            check(lib.mgrt_upload(C.c_void_p(ptr), C.c_void_p(t.data_ptr()), t.numel(), None))
+
+        def sendrecv(ctx, n, peers, send, recv, nbytes):
+            try:
+                ops, landing = [], []
+                for k in range(n):
+                    peer = dist.get_global_rank(group, peers[k]) if group is not None else peers[k]
+                    out = down(send[k], nbytes[k])
+                    inc = torch.empty(nbytes[k], dtype=torch.uint8)
+                    ops += [dist.P2POp(dist.isend, out, peer, group), dist.P2POp(dist.irecv, inc, peer, group)]
+                    landing.append((recv[k], inc))
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                for ptr, t in landing:
+                    up(ptr, t)
+                return 0
+            except Exception as err:  # an exception must not cross the C boundary
+                print("GlooTransport.sendrecv: %r" % (err,), flush=True)
+                return 1
+
+        def allgather(ctx, send, recv, nbytes):
+            try:
+                src = down(send, nbytes)
+                parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+                dist.all_gather(parts, src, group=group)
+                up(recv, torch.cat(parts))
+                return 0
+            except Exception as err:
+                print("GlooTransport.allgather: %r" % (err,), flush=True)
+                return 1
+
+        def allreduce(ctx, value):
+            try:
+                t = down(value, 8).view(torch.float64)
+                dist.all_reduce(t, group=group)
+                up(value, t.view(torch.uint8))
+                return 0
+            except Exception as err:
+                print("GlooTransport.allreduce: %r" % (err,), flush=True)
+                return 1
+
+        self._keep = (SENDRECV_FN(sendrecv), ALLGATHER_FN(allgather), ALLREDUCE_FN(allreduce))
+
+    def struct(self):
+        t = Transport()
+        t.kind, t.rank, t.nranks = TRANSPORT_CALLBACK, self.rank, self.world
+        t.sendrecv, t.allgather, t.allreduce_sum = self._keep
+        return t
+
+
+class SlabPlan:
+    """mgrt_slab_plan: the V-cycle on this rank's y-slab of a 3D grid (shape = whole grid, (nz, ny, nx)).
+
+    transport: "rccl" (every rank passes the same `rccl_id` from rccl_unique_id()), a GlooTransport, or
+    None with (rank, nranks) for the stand-alone share of one rank."""
+
+    def __init__(self, shape, dtype, transport=None, rank=0, nranks=1, rccl_id=None, faces=ALL_DIRICHLET, zfull=True,
+                 use_graph=True, crossover=129 ** 3, stream=None):
+        import torch
+        d = SlabDesc()
+        d.nz, d.ny, d.nx = shape
+        d.elem_size = {torch.float32: 4, torch.float64: 8}[dtype]
+        d.face = (C.c_int * 6)(*faces)
+        d.zfull, d.use_graph, d.crossover = int(zfull), int(use_graph), int(crossover)
+        if transport == "rccl":
+            t = Transport()
+            t.kind, t.rank, t.nranks = TRANSPORT_RCCL, rank, nranks
+            t.rccl_id = (C.c_ubyte * 128)(*rccl_id)
+        elif transport is None:
+            t = Transport()
+            t.kind, t.rank, t.nranks = TRANSPORT_NONE, rank, nranks
+        else:
+            t = transport.struct()
+        self._transport = transport  # keeps the callbacks alive
+        self.shape, self.dtype = tuple(shape), dtype
+        self.stream = stream if stream is not None else torch.cuda.Stream()
+        self._h = C.c_void_p()
+        check(load().mgrt_slab_plan_create(C.byref(self._h), C.byref(d), C.byref(t), C.c_void_p(self.stream.cuda_stream)))
+
+    def close(self):
+        if self._h:
+            check(load().mgrt_slab_plan_destroy(self._h))
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def distributed_levels(self):
+        return load().mgrt_slab_plan_distributed_levels(self._h)
+
+    @property
+    def uses_graph(self):
+        return bool(load().mgrt_slab_plan_uses_graph(self._h))
+
+    def rows(self):
+        """(lo, hi, own_lo, own_hi): global rows of level 0 stored and owned by this rank."""
+        v = [C.c_int() for _ in range(4)]
+        check(load().mgrt_slab_plan_rows(self._h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def scatter(self, whole):
+        lo, hi, _, _ = self.rows()
+        return whole[:, lo:hi, :].contiguous()
+
+    def owned(self, local):
+        lo, _, a, b = self.rows()
+        return local[:, a - lo:b - lo, :]
+
+    def vcycle(self, u, f, omega=1.0, a1=2, a2=2, v=1, ncycles=1, history=False):
+        """In place on this rank's rows (halo included); the work is queued on self.stream, which first
+        waits for the current stream.  Returns the residual history over the whole grid, or None."""
+        import torch
+        assert u.is_contiguous() and f.is_contiguous() and u.dtype == self.dtype and f.dtype == self.dtype
+        lo, hi, _, _ = self.rows()
+        assert tuple(u.shape) == (self.shape[0], hi - lo, self.shape[2]) == tuple(f.shape)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        hist = (C.c_double * (ncycles + 1))() if history else None
+        check(load().mgrt_slab_plan_vcycle(self._h, _p(u), _p(f), omega, a1, a2, v, ncycles, hist))
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return list(hist) if history else None

@@ -3,8 +3,9 @@ torch.distributed.run; exits non-zero when this rank's rows differ from the whol
 
   dist_worker.py BACKEND NZ NY NX DTYPE OMEGA A1 A2 V NCYCLES ZFULL CROSSOVER
 
-BACKEND cpu: gloo, CPU tensors, oracle-backed kernels.  BACKEND gpu: gloo with host staging, every
-rank on cuda:0, the HIP kernels (for a one-GPU box)."""
+BACKEND cpu: gloo, CPU tensors, oracle-backed kernels, the Python driver (multigrid_amd/dist.py).
+BACKEND gpu: the same driver with the HIP kernels, every rank on cuda:0, gloo with host staging.
+BACKEND native: mgrt_slab_plan of libmgrt.so (the C++ driver) on cuda:0 with callbacks over gloo."""
 import os
 import sys
 
@@ -29,7 +30,7 @@ def main():
     import _oracle
     from multigrid_amd import dist as slab
     o = _oracle.load("mgo")
-    o.set_num_threads(1)
+    o.set_num_threads(1 if nz * ny * nx < 2e7 else 8)
     shape = (nz, ny, nx)
     rng = np.random.default_rng(1234)
     f = rng.standard_normal(shape).astype(dt)
@@ -56,12 +57,20 @@ def main():
         torch.cuda.set_device(0)
         kernels.init(0)
         device = torch.device("cuda", 0)
-    cyc = slab.SlabCycle(shape, tdt, kernels=kernels, device=device, zfull=zfull, crossover=crossover)
-    assert cyc.ndist >= 1, "this case does not split: pick a larger grid or a smaller crossover"
     to = (lambda a: torch.from_numpy(a.copy())) if device is None else (lambda a: torch.from_numpy(a.copy()).to(device))
+    if backend == "native":
+        cyc = kernels.SlabPlan(shape, tdt, transport=kernels.GlooTransport(), zfull=zfull, crossover=crossover)
+        ndist = cyc.distributed_levels
+        lo, hi, a, b = cyc.rows()
+    else:
+        cyc = slab.SlabCycle(shape, tdt, kernels=kernels, device=device, zfull=zfull, crossover=crossover)
+        ndist = cyc.ndist
+        lo, hi, a, b = cyc.local_rows()
+    assert ndist >= 1, "this case does not split: pick a larger grid or a smaller crossover"
     ul, fl = cyc.scatter(to(u0)), cyc.scatter(to(f))
     hist = cyc.vcycle(ul, fl, omega, a1, a2, v, ncycles, history=True)
-    lo, hi, a, b = cyc.local_rows()
+    if device is not None:
+        torch.cuda.synchronize()
     mine = cyc.owned(ul).cpu().numpy()
     want = ref[:, a:b, :]
     ok = np.array_equal(mine.view(np.uint8), want.view(np.uint8))
@@ -69,7 +78,7 @@ def main():
     if not ok or not hok:
         bad = np.argwhere(mine != want)
         print("rank %d/%d rows [%d,%d) ndist %d: mismatch at %d cells, first %s; hist %s vs %s"
-              % (rank, world, a, b, cyc.ndist, len(bad), bad[:3].tolist(), hist, hist_ref), flush=True)
+              % (rank, world, a, b, ndist, len(bad), bad[:3].tolist(), hist, hist_ref), flush=True)
     flag = torch.tensor([0 if ok and hok else 1])
     dist.all_reduce(flag)
     cyc.close()

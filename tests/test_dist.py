@@ -79,3 +79,18 @@ GPU_CASES = [
 def test_slab_cycle_gpu_matches_whole_grid(case):
     world, shape, dtype, omega, a1, a2, v, ncycles, zfull, crossover = case
     launch(world, "gpu", shape, dtype, omega, a1, a2, v, ncycles, zfull, crossover)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GPU_CASES, ids=lambda c: "w%d-%s-%s" % (c[0], "x".join(map(str, c[1])), c[2]))
+def test_native_slab_plan_matches_whole_grid(case):
+    """mgrt_slab_plan (the C++ driver inside libmgrt.so) with its callback transport."""
+    world, shape, dtype, omega, a1, a2, v, ncycles, zfull, crossover = case
+    launch(world, "native", shape, dtype, omega, a1, a2, v, ncycles, zfull, crossover)
+
+
+@pytest.mark.gpu
+def test_native_slab_plan_513_cubed_two_ranks():
+    """The benchmark's grid cut in two: one V(2,2) cycle at 513^3, every rank's rows bit for bit those of
+    the oracle's whole-grid cycle (two levels cut, 129^3 and below whole on both ranks)."""
+    launch(2, "native", (513, 513, 513), "f32", 1.0, 2, 2, 1, 1, True, 129 ** 3, timeout=900)
