@@ -657,8 +657,10 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
     // Latency-bound levels: strips of two rows.  From about 100^2 columns up as two stages of one
     // iteration each (16 wavefronts a block; measured 105 vs 114 us at 257^3, 54 vs 59 at 129^3), below
     // that as one stage (20 vs 23 us at 33^3: few blocks, and the second stage only adds its lag).
-    if (small && (long long)g->nx * g->ny >= 100LL * 100LL)
-        return launch<R, 1, 2, 8, 4, false, false, 2>(g, out, in, f, omega, zcount, hs);
+    if constexpr (sizeof(R) == 4) { // 16 wavefronts a block leave 128 registers a lane: tight for 8-byte elements
+        if (small && (long long)g->nx * g->ny >= 100LL * 100LL)
+            return launch<R, 1, 2, 8, 4, false, false, 2>(g, out, in, f, omega, zcount, hs);
+    }
     return small ? launch<R, 2, 2, sizeof(R) == 4 ? 8 : 12, 3>(g, out, in, f, omega, zcount, hs)
                  : launch<R, 2, C::SR2, C::NW2, C::PF2>(g, out, in, f, omega, zcount, hs);
 }
