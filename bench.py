@@ -13,9 +13,10 @@ of that workload's dominant kernel and the CPU oracle timed on the same extents.
 
 For N > 1 there is one process per GPU (3d513 only): started by the caller with torch.distributed.run,
 or, when WORLD_SIZE is not set, started here as child processes before anything touches a GPU.  The
-grid is cut into N slabs along y (multigrid_amd/dist.py); total work is fixed: strong scaling.  On a
-box with fewer than N GPUs the ranks share the devices over gloo (a rehearsal of the path, marked as
-such in the output, not a measurement).
+grid is cut into N slabs along y (mgrt_slab_plan of libmgrt.so: halos over RCCL, a whole cycle of a
+rank replayed from one hipGraph); total work is fixed: strong scaling.  On a box with fewer than N GPUs
+the ranks share the devices and the halos go through host callbacks over gloo (a rehearsal of the path,
+marked as such in the output, not a measurement).
 """
 import argparse
 import json
@@ -191,10 +192,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("gloo")
     _lib.init(local)
 
     shape, dtname, faces, _, workload = CONFIGS[args.config]
@@ -213,25 +211,57 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.all_reduce(sync.cpu() if rehearse else sync)
+            dist.all_reduce(sync.cpu())
             torch.cuda.synchronize()
 
     layout = None
     if world > 1:
-        from multigrid_amd import dist as slab
-        cyc = slab.SlabCycle(shape, tdt, device=dev, zfull=True, crossover=args.crossover,
-                             use_graph=not args.no_graph)
+        # mgrt_slab_plan: this rank's slab, halos over RCCL on the plan's stream, a cycle per graph launch.
+        # torch.distributed (gloo) only hands the RCCL id round and closes the timed region.
+        def make_plan(transport, rid):
+            return _lib.SlabPlan(shape, tdt, transport=transport, rank=rank, nranks=world, rccl_id=rid, faces=faces,
+                                 zfull=True, crossover=args.crossover, use_graph=not args.no_graph)
+        transport_note = "host callbacks over gloo (rehearsal)"
+        cyc = None
+        if not rehearse:
+            # every rank must end up on the same transport: agree on whether RCCL came up everywhere
+            err = ""
+            try:
+                box = [_lib.rccl_unique_id() if rank == 0 else None]
+            except _lib.MgrtError as e:
+                box, err = [None], str(e)
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is not None:
+                try:
+                    cyc = make_plan("rccl", box[0])
+                except _lib.MgrtError as e:
+                    err = str(e)
+            bad = torch.tensor([0 if cyc is not None else 1])
+            dist.all_reduce(bad)
+            if bad.item():
+                if cyc is not None:
+                    cyc.close()
+                    cyc = None
+                transport_note = "host callbacks over gloo: RCCL did not come up on %d rank(s)%s" % (
+                    bad.item(), " (" + err + ")" if err else "")
+            else:
+                transport_note = "RCCL"
+        if cyc is None:
+            cyc = make_plan(_lib.GlooTransport(), None)
         fl, ul = cyc.scatter(f), cyc.scatter(u)
         del f, u
-        r0 = cyc.residual_norm(ul, fl)
+        r0 = cyc.vcycle(ul, fl, ncycles=0, history=True)[0]
         cyc.vcycle(ul, fl, 1.0, 2, 2, 1, args.warmup)
         barrier()
         t0 = time.perf_counter()
         cyc.vcycle(ul, fl, 1.0, 2, 2, 1, args.steps)
         barrier()
         dt = time.perf_counter() - t0
-        r1 = cyc.residual_norm(ul, fl)
-        layout = cyc.describe()
+        r1 = cyc.vcycle(ul, fl, ncycles=0, history=True)[0]
+        lo, hi, a, b = cyc.rows()
+        layout = {"rank0_rows_owned": b - a, "halo_rows": 4, "levels_cut": cyc.distributed_levels,
+                  "whole_on_every_rank_from_points": args.crossover, "cycle_in_one_graph": cyc.uses_graph,
+                  "transport": transport_note}
         cyc.close()
         del fl, ul
         f = make_problem(shape, tdt, faces, dev)
@@ -289,7 +319,7 @@ def main():
         t_kernel = e0.elapsed_time(e1) * 1e-3 / reps
 
     if world > 1:
-        t = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 

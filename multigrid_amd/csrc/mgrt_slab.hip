@@ -128,6 +128,7 @@ struct mgrt_slab_plan {
     int norms_cap = 0;
     hipGraphExec_t exec = nullptr;
     bool graph_failed = false; // capture or instantiation was refused once: cycles are launched directly
+    bool warmed = false;       // one cycle has run outside a capture (RCCL sets its connections up on first use)
     struct Key {
         void *u;
         const void *f;
@@ -385,8 +386,10 @@ void drop_graph(mgrt_slab_plan *p)
 // transport can be captured; launched directly otherwise, and for good once a capture was refused.
 template <class R> mgrt_status run_cycle(mgrt_slab_plan *p, R *u, const R *f, R omega, int a1, int a2, int v)
 {
-    if (!p->desc.use_graph || !capturable(p) || p->graph_failed)
+    if (!p->desc.use_graph || !capturable(p) || p->graph_failed || !p->warmed) {
+        p->warmed = true;
         return cycle_body<R>(p, u, f, omega, a1, a2, v);
+    }
     const mgrt_slab_plan::Key key{u, f, (double)omega, a1, a2, v};
     const bool same = p->exec && p->key.u == key.u && p->key.f == key.f && p->key.omega == key.omega && p->key.a1 == key.a1 &&
                       p->key.a2 == key.a2 && p->key.v == key.v;
