@@ -101,6 +101,10 @@ struct mgrt_slab_plan {
     mgrt_slab_desc desc;
     mgrt_transport tr;
     hipStream_t stream = nullptr;
+    // halos that independent work can hide travel on a stream of their own, forked from and joined to
+    // `stream` by events (inside a captured cycle these become edges of the graph)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     Rccl *nc = nullptr;
     void *comm = nullptr;
     int rank = 0, world = 1, ndist = 0;
@@ -160,23 +164,54 @@ int distributed_levels(int nx, int ny, int nz, int world, long long crossover)
 }
 
 // rows [r0, r0 + kHalo) of every plane of `field` <-> a dense staging buffer
-mgrt_status pack_rows(const mgrt_slab_plan *p, const mgrt_slab_plan::Level &L, void *dst, const void *field, int r0)
+mgrt_status pack_rows(const mgrt_slab_plan *p, const mgrt_slab_plan::Level &L, void *dst, const void *field, int r0,
+                      hipStream_t on)
 {
     const size_t w = elem(p), row = (size_t)L.g.pitch * w;
     MGRT_HIP(hipMemcpy2DAsync(dst, kHalo * row, (const char *)field + (size_t)r0 * row, (size_t)L.g.slab * w, kHalo * row,
-                              (size_t)L.nz, hipMemcpyDeviceToDevice, p->stream));
+                              (size_t)L.nz, hipMemcpyDeviceToDevice, on));
     return MGRT_OK;
 }
-mgrt_status unpack_rows(const mgrt_slab_plan *p, const mgrt_slab_plan::Level &L, void *field, const void *src, int r0)
+mgrt_status unpack_rows(const mgrt_slab_plan *p, const mgrt_slab_plan::Level &L, void *field, const void *src, int r0,
+                        hipStream_t on)
 {
     const size_t w = elem(p), row = (size_t)L.g.pitch * w;
     MGRT_HIP(hipMemcpy2DAsync((char *)field + (size_t)r0 * row, (size_t)L.g.slab * w, src, kHalo * row, kHalo * row,
-                              (size_t)L.nz, hipMemcpyDeviceToDevice, p->stream));
+                              (size_t)L.nz, hipMemcpyDeviceToDevice, on));
     return MGRT_OK;
 }
 
-// Fill the halo rows of `field` on level L from the neighbours' owned rows.
-mgrt_status exchange(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, void *field)
+// Fill the halo rows of `field` on level L from the neighbours' owned rows; the work is queued on `on`.
+mgrt_status exchange_on(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, void *field, hipStream_t on);
+
+mgrt_status exchange(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, void *field) { return exchange_on(p, L, field, p->stream); }
+
+// The same on the side stream: exchange_begin returns at once, the halo rows are valid after exchange_end.
+// What is queued on the main stream in between runs beside the transfer and must not touch halo rows.
+// (With the callback transport the host blocks inside exchange_begin, so nothing overlaps; the path is
+// the same, which is how the one-GPU tests cover it.)
+bool overlaps(const mgrt_slab_plan *p) { return p->world > 1 && p->side; }
+
+mgrt_status exchange_begin(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, void *field)
+{
+    if (!overlaps(p))
+        return exchange(p, L, field);
+    MGRT_HIP(hipEventRecord(p->ev_fork, p->stream));
+    MGRT_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+    if (mgrt_status st = exchange_on(p, L, field, p->side))
+        return st;
+    MGRT_HIP(hipEventRecord(p->ev_join, p->side));
+    return MGRT_OK;
+}
+
+mgrt_status exchange_end(mgrt_slab_plan *p)
+{
+    if (overlaps(p))
+        MGRT_HIP(hipStreamWaitEvent(p->stream, p->ev_join, 0));
+    return MGRT_OK;
+}
+
+mgrt_status exchange_on(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, void *field, hipStream_t on)
 {
     if (p->world == 1)
         return MGRT_OK;
@@ -185,15 +220,15 @@ mgrt_status exchange(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, void *field)
     bool has[2] = {peer[0] >= 0, peer[1] < p->world};
     for (int k = 0; k < 2; ++k)
         if (has[k])
-            if (mgrt_status st = pack_rows(p, L, L.sendbuf[k], field, send_row[k]))
+            if (mgrt_status st = pack_rows(p, L, L.sendbuf[k], field, send_row[k], on))
                 return st;
     if (p->tr.kind == MGRT_TRANSPORT_RCCL) {
         Rccl *nc = p->nc;
         MGRT_NCCL(nc->GroupStart());
         for (int k = 0; k < 2; ++k)
             if (has[k]) {
-                MGRT_NCCL(nc->Send(L.sendbuf[k], L.halo_bytes, kNcclChar, peer[k], p->comm, p->stream));
-                MGRT_NCCL(nc->Recv(L.recvbuf[k], L.halo_bytes, kNcclChar, peer[k], p->comm, p->stream));
+                MGRT_NCCL(nc->Send(L.sendbuf[k], L.halo_bytes, kNcclChar, peer[k], p->comm, on));
+                MGRT_NCCL(nc->Recv(L.recvbuf[k], L.halo_bytes, kNcclChar, peer[k], p->comm, on));
             }
         MGRT_NCCL(nc->GroupEnd());
     } else if (p->tr.kind == MGRT_TRANSPORT_CALLBACK) {
@@ -203,17 +238,17 @@ mgrt_status exchange(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, void *field)
         for (int k = 0; k < 2; ++k)
             if (has[k])
                 peers[n] = peer[k], send[n] = L.sendbuf[k], recv[n] = L.recvbuf[k], bytes[n] = L.halo_bytes, ++n;
-        MGRT_HIP(hipStreamSynchronize(p->stream));
+        MGRT_HIP(hipStreamSynchronize(on));
         if (p->tr.sendrecv(p->tr.ctx, n, peers, send, recv, bytes) != 0)
             return fail(MGRT_E_TRANSPORT, "mgrt_slab_plan: the sendrecv callback failed");
     } else { // no wire: what would be received is what was packed (same bytes moved on the device)
         for (int k = 0; k < 2; ++k)
             if (has[k])
-                MGRT_HIP(hipMemcpyAsync(L.recvbuf[k], L.sendbuf[k], L.halo_bytes, hipMemcpyDeviceToDevice, p->stream));
+                MGRT_HIP(hipMemcpyAsync(L.recvbuf[k], L.sendbuf[k], L.halo_bytes, hipMemcpyDeviceToDevice, on));
     }
     for (int k = 0; k < 2; ++k)
         if (has[k])
-            if (mgrt_status st = unpack_rows(p, L, field, L.recvbuf[k], recv_row[k]))
+            if (mgrt_status st = unpack_rows(p, L, field, L.recvbuf[k], recv_row[k], on))
                 return st;
     return MGRT_OK;
 }
@@ -303,15 +338,32 @@ mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1,
         return st;
     const bool last = l + 1 == p->ndist;
     for (int it = 0; it < v; ++it) {
-        if (!halo_valid) {
-            if (mgrt_status st = exchange(p, L, cur))
+        // residual on the owned rows and one more on each side: what the restriction reads.  The rows
+        // whose stencil stays inside the owned rows are formed while the halo of the unknown travels,
+        // the two rows at either end afterwards.
+        const int rlo = L.y0 > 0 ? L.own0 - 1 : L.own0, rhi = L.y1 < L.gny ? L.own1 + 1 : L.own1;
+        if (!halo_valid && L.own1 - L.own0 > 2) {
+            if (mgrt_status st = exchange_begin(p, L, cur))
+                return st;
+            const int ilo = L.own0 + 1, ihi = L.own1 - 1;
+            if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, ilo, ihi, s))
+                return st;
+            if (mgrt_status st = exchange_end(p))
                 return st;
             halo_valid = true;
+            if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, rlo, ilo, s))
+                return st;
+            if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, ihi, rhi, s))
+                return st;
+        } else {
+            if (!halo_valid) {
+                if (mgrt_status st = exchange(p, L, cur))
+                    return st;
+                halo_valid = true;
+            }
+            if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, rlo, rhi, s))
+                return st;
         }
-        // residual on the owned rows and one more on each side: what the restriction reads
-        const int rlo = L.y0 > 0 ? L.own0 - 1 : L.own0, rhi = L.y1 < L.gny ? L.own1 + 1 : L.own1;
-        if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, rlo, rhi, s))
-            return st;
         const R *e_local;
         const mgrt_grid *egrid;
         if (last) {
@@ -521,6 +573,13 @@ mgrt_status mgrt_slab_plan_create(mgrt_slab_plan **plan, const mgrt_slab_desc *d
         if (e != 0)
             return bail(fail(MGRT_E_TRANSPORT, "ncclCommInitRank: %s", p->nc->GetErrorString(e)));
     }
+    if (p->world > 1) {
+        hipError_t es = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+        if (es == hipSuccess) es = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
+        if (es == hipSuccess) es = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
+        if (es != hipSuccess)
+            return bail(fail((mgrt_status)es, "mgrt_slab_plan_create: %s", hipGetErrorString(es)));
+    }
     p->ndist = distributed_levels(d->nx, d->ny, d->nz, p->world, d->crossover);
     const int align = 1 << p->ndist;
     const int q = (d->ny - 1) / (p->world * align);
@@ -620,6 +679,12 @@ mgrt_status mgrt_slab_plan_destroy(mgrt_slab_plan *p)
         (void)hipFree(a);
     if (p->comm && p->nc)
         (void)p->nc->CommDestroy(p->comm);
+    if (p->side) {
+        (void)hipStreamSynchronize(p->side);
+        (void)hipStreamDestroy(p->side);
+    }
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     delete p;
     return MGRT_OK;
 }
