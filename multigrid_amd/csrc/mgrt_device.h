@@ -75,6 +75,11 @@ __device__ __forceinline__ void buf_load_hidden(double &v, desc_t r, unsigned of
 {
     asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(v) : "v"(off), "s"(r) : "memory");
 }
+// one byte per lane, zero-extended (cell classes)
+__device__ __forceinline__ void buf_load_hidden_u8(int &v, desc_t r, unsigned off)
+{
+    asm volatile("buffer_load_ubyte %0, %1, %2, 0 offen" : "=v"(v) : "v"(off), "s"(r) : "memory");
+}
 template <int N, class R> __device__ __forceinline__ void wait_slot2(R &a, R &b, R &c, R &d)
 {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N));

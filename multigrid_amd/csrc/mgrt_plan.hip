@@ -114,11 +114,16 @@ mgrt_status run_bottom(mgrt_plan *p, int l, R *u, const R *u_in, const R *f, R o
     return bottom_cycle(p->desc.dim, n - l, nx, ny, nz, p->lv[l].g.face, p->desc.zfull, u, u_in, f, omega, a1, a2, v, p->stream);
 }
 
-// The fused sweep kernels cover analytic-box levels; levels with a byte map smooth in place with
-// the single-colour kernel.
+// The fused 3D sweep covers analytic boxes and byte maps alike (the variants that carry the residual or
+// the correction along: boxes only); 2D levels with a byte map smooth in place with the single-colour
+// kernel.
 bool sweepable(const mgrt_plan *p, const mgrt_grid &g)
 {
-    return !p->desc.no_fuse && g.cells == nullptr && (g.dim == 2 || plane_offsets_fit(&g, (size_t)p->desc.elem_size));
+    if (p->desc.no_fuse)
+        return false;
+    if (g.dim == 2)
+        return g.cells == nullptr; // the 2D tile kernels know the analytic box only
+    return plane_offsets_fit(&g, (size_t)p->desc.elem_size);
 }
 
 // `a` smoothing iterations on *cur, as `nsweeps` out-of-place fused sweeps that ping-pong between
@@ -187,7 +192,7 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
     // precision when that sweep does two iterations.
     const bool res_in_sweep =
         n1 > 0 && v > 0 && recurses(L.g) &&
-        (L.g.dim == 2 || (sizeof(R) == 4 && L.g.dim == 3 && !latency_bound_level(L.g)));
+        (L.g.dim == 2 || (sizeof(R) == 4 && L.g.dim == 3 && !latency_bound_level(L.g) && !L.g.cells));
     const bool correct_in_sweep =
         n2 > 0 && a2 > 0 && v > 0 && recurses(L.g) &&
         (L.g.dim == 2 || correct_sweep_3d_supported(&L.g, sizeof(R), n2 < a2 ? 2 : 1));

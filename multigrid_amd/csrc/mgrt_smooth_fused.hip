@@ -88,7 +88,13 @@ template <class R> __device__ __forceinline__ R dot4(R a0, R a1, R a2, R a3, R b
 // wavefront then issues half the instructions per time step; on levels whose sweep time is the
 // latency of a step rather than bandwidth that is what counts.  The second group runs
 // LAG = 2*ITERS + 1 steps behind the first; both share the one barrier per step.
-template <class R, int ITERS, int SR, int NW, int PD, bool OMEGA1, bool RES, bool COR = false, int STAGES = 1>
+//
+// MAP: the domain is described by one byte per point (g.cells) instead of six face classes.  The
+// bytes of a plane are prefetched beside its values (SR more loads per lane and step), packed two bits
+// a row into one register per plane in flight, and looked up where the box variant uses per-lane
+// constants; nothing else changes, so any domain a BorderHandler can describe takes the fused sweep.
+template <class R, int ITERS, int SR, int NW, int PD, bool OMEGA1, bool RES, bool COR = false, int STAGES = 1,
+          bool MAP = false>
 __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid g, const R *__restrict__ in,
                                                               R *__restrict__ out, const R *__restrict__ f,
                                                               R *__restrict__ res, R omega, int zcount, int ntx,
@@ -97,6 +103,7 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     static_assert(SR % 2 == 0, "rows are handled in pairs");
     static_assert(!COR || (PD == 2 && !RES), "the corrected input is built for a prefetch depth of two planes");
     static_assert(STAGES == 1 || (STAGES == 2 && !RES && !COR), "stages hand on whole smoothed planes only");
+    static_assert(!MAP || (STAGES == 1 && !RES && !COR && SR <= 16), "the byte-map variant is the plain sweep");
     constexpr int NP = 2 * ITERS, J = SR / 2;    // colour passes per stage
     constexpr int H = NP * STAGES + (RES ? 1 : 0); // halo rings consumed by all stages together
     constexpr int LAG = NP + 1;                  // steps between a plane leaving one stage and entering the next
@@ -157,6 +164,26 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
         else if (x == g.nx - 1) c = g.face[1];
         rowcls[r] = c;
     }
+    // byte map: in-plane byte offset per row (element offset: one byte a point), and OUTER (01) in the
+    // two bits of every row that lies outside the grid, where the dropped load returns 0 = INNER
+    unsigned coff[MAP ? SR : 1];
+    int deadbits = 0, shc[2][J];
+    if constexpr (MAP) {
+        static_assert(MGRT_CELL_OUTER == 1 && MGRT_CELL_INNER == 0, "dropped class loads must read as a mask of OUTER");
+        const unsigned cplane = (unsigned)(g.pitch * (long long)g.ny);
+        (void)cplane;
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+            coff[r] = off[r] == kDrop ? kDrop : off[r] / (unsigned)sizeof(R);
+            if (off[r] == kDrop)
+                deadbits |= MGRT_CELL_OUTER << (2 * r);
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) { // row 2j + (s0 ^ c) holds the colour-c point of pair j
+            shc[0][j] = 2 * (2 * j + s0);
+            shc[1][j] = 2 * (2 * j + (s0 ^ 1));
+        }
+    }
     bool interior[2][J], latdir[2][J], latfix[2][J]; // latfix: lateral Dirichlet column
 #pragma unroll
     for (int j = 0; j < J; ++j) { // row 2j + s0 of pair j holds the colour-0 point
@@ -181,7 +208,8 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     constexpr int lag = STG * LAG;
     constexpr int WB = STG * NW; // this stage's wavefronts in bnd
     constexpr int kStores = LAST ? (RES ? 2 * SR : SR) : 0;            // per step
-    constexpr int kYounger = kStores + (PD - 1) * (2 * SR + kStores); // see wait_slot
+    constexpr int kLoads = MAP ? 3 * SR : 2 * SR;                     // per step
+    constexpr int kYounger = kStores + (PD - 1) * (kLoads + kStores); // see wait_slot
     static_assert(kYounger < 64, "too many vector-memory operations in flight for a counted wait");
 #ifdef MGRT_STAMPS
     unsigned long long acc[8] = {}, tprev = 0;
@@ -235,6 +263,19 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
         }
     };
     R pu[PD][SR], pf[PD][SR];
+    int pk[PD][MAP ? SR : 1], K[MAP ? ND : 1]; // class bytes on their way in, packed classes of the planes in flight
+    const unsigned cells_bytes = MAP ? (unsigned)(g.pitch * (long long)g.ny) : 0u;
+    auto pin_cells = [&](int(&a)[MAP ? SR : 1]) { // as pin_coarse
+        if constexpr (MAP) {
+#pragma unroll
+            for (int r = 0; r < SR; ++r)
+                asm volatile("" : "+v"(a[r]));
+        }
+    };
+    if constexpr (MAP) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) K[d] = 0x55555555; // OUTER everywhere: planes below the grid
+    }
     if constexpr (FIRST) {
 #pragma unroll
         for (int k = 0; k < PD; ++k) {
@@ -245,13 +286,21 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                 buf_load_hidden(pu[k][r], ru, off[r]);
                 buf_load_hidden(pf[k][r], rf, off[r]);
             }
+            if constexpr (MAP) {
+                const desc_t rk = plane_desc(g.cells + zo, cells_bytes);
+#pragma unroll
+                for (int r = 0; r < SR; ++r)
+                    buf_load_hidden_u8(pk[k][r], rk, coff[r]);
+            }
         }
     }
     auto drain0 = [&]() {
         if constexpr (FIRST) {
 #pragma unroll
-            for (int k = 0; k < PD; ++k)
+            for (int k = 0; k < PD; ++k) {
                 wait_slot<0>(pu[k], pf[k]);
+                pin_cells(pk[k]);
+            }
         }
         pin_coarse(pe);
         pin_coarse(Eb);
@@ -277,6 +326,7 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
         desc_t d_res = plane_desc(RES ? res + slab * (i0 - DR) : out, plane_bytes);
         // coarse plane prefetched at the group's first (even) step: the upper one of fine plane i0 + PD
         desc_t d_e = plane_desc(COR ? eb + cf.slab * ((i0 + PD) / 2 + 1) : eb, cplane_bytes);
+        desc_t d_k = plane_desc(MAP ? g.cells + slab * (i0 + PD) : (const unsigned char *)f, cells_bytes);
         const unsigned long long slab_bytes = (unsigned long long)slab * sizeof(R);
         auto advance = [&](desc_t &d, unsigned long long by) {
             const unsigned long long a = (((unsigned long long)(unsigned)d.y << 32) | (unsigned)d.x) + by;
@@ -307,6 +357,15 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                         wait_slot<kYoungerOdd>(pu[ps], pf[ps]);
                     else
                         wait_slot<kYounger>(pu[ps], pf[ps]);
+                    pin_cells(pk[ps]);
+                    if constexpr (MAP) {
+                        int packed = deadbits;
+#pragma unroll
+                        for (int r = 0; r < SR; ++r)
+                            packed |= pk[ps][r] << (2 * r);
+                        K[PH(0)] = packed;
+                        asm volatile("" : "+v"(K[PH(0)])); // made before the slot is requested again
+                    }
                 }
                 if (FAST) {
                     MGRT_STAMP(0); // waiting for the prefetched plane
@@ -369,6 +428,12 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                     for (int r = 0; r < SR; ++r) {
                         buf_load_hidden(pu[ps][r], ru, off[r]);
                         buf_load_hidden(pf[ps][r], rf, off[r]);
+                    }
+                    if constexpr (MAP) {
+                        const desc_t rk = FAST ? d_k : plane_desc(g.cells + zo, cells_bytes);
+#pragma unroll
+                        for (int r = 0; r < SR; ++r)
+                            buf_load_hidden_u8(pk[ps][r], rk, coff[r]);
                     }
                     if constexpr (COR) {
                         if ((u & 1) == 0) { // the upper coarse plane of fine plane i + PD
@@ -449,8 +514,13 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                             // under a branch on take_gs, and the exec-mask blocks that result
                             // serialise the independent updates of a step and their LDS reads.
                             asm("" : "+v"(gs));
-                            const bool take_gs = FAST ? interior[c][j] : (interior[c][j] && zin);
-                            const bool take_f = FAST ? latfix[c][j] : (interior[c][j] ? zdir : latdir[c][j]);
+                            bool take_gs = FAST ? interior[c][j] : (interior[c][j] && zin);
+                            bool take_f = FAST ? latfix[c][j] : (interior[c][j] ? zdir : latdir[c][j]);
+                            if constexpr (MAP) { // the class of this very point, from the map
+                                const int cls = (K[PH(d)] >> shc[c][j]) & 3;
+                                take_gs = cls == MGRT_CELL_INNER;
+                                take_f = cls == MGRT_CELL_DIRICHLET;
+                            }
                             C[c][PH(d)][j] = take_gs ? gs : (take_f ? fv : own);
                         }
                     }
@@ -519,6 +589,8 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
 #endif
                 }
                 if (FAST && (FIRST || LAST)) {
+                    if (MAP)
+                        advance(d_k, (unsigned long long)slab);
                     advance(d_in, slab_bytes), advance(d_f, slab_bytes), advance(d_out, slab_bytes);
                     if (RES)
                         advance(d_res, slab_bytes);
@@ -536,8 +608,10 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     auto drain = [&]() {
         if constexpr (FIRST) {
 #pragma unroll
-            for (int k = 0; k < PD; ++k)
+            for (int k = 0; k < PD; ++k) {
                 wait_slot<0>(pu[k], pf[k]);
+                pin_cells(pk[k]);
+            }
         }
         pin_coarse(pe);
     };
@@ -584,7 +658,7 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     }
 }
 
-template <class R, int ITERS, int SR, int NW, int PD, bool RES = false, bool COR = false, int STAGES = 1>
+template <class R, int ITERS, int SR, int NW, int PD, bool RES = false, bool COR = false, int STAGES = 1, bool MAP = false>
 mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, int zcount, hipStream_t hs,
                    R *res = nullptr, const mgrt_grid *cg = nullptr, const R *e = nullptr)
 {
@@ -601,9 +675,9 @@ mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega,
         cf.nx = cg->nx, cf.ny = cg->ny, cf.nz = cg->nz, cf.y0 = cg->y0;
     }
     if (omega == (R)1)
-        k_smooth3d_fused<R, ITERS, SR, NW, PD, true, RES, COR, STAGES><<<grid, NW * STAGES * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
+        k_smooth3d_fused<R, ITERS, SR, NW, PD, true, RES, COR, STAGES, MAP><<<grid, NW * STAGES * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
     else
-        k_smooth3d_fused<R, ITERS, SR, NW, PD, false, RES, COR, STAGES><<<grid, NW * STAGES * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
+        k_smooth3d_fused<R, ITERS, SR, NW, PD, false, RES, COR, STAGES, MAP><<<grid, NW * STAGES * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
     MGRT_HIP(hipGetLastError());
     return MGRT_OK;
 }
@@ -629,8 +703,9 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
     MGRT_REQUIRE(out != in && out != f, "mgrt_smooth_sweep: out must not alias in or f");
     MGRT_REQUIRE(!res || (res != out && res != in && res != f), "mgrt_smooth_sweep_residual: r must not alias another field");
     MGRT_REQUIRE(zcount >= 0 && zcount <= g->nz, "mgrt_smooth_sweep: zcount %d outside [0,%d]", zcount, g->nz);
-    if (g->cells)
-        return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep: byte cell maps are not supported, use mgrt_smooth_pass");
+    if (g->cells && (g->dim != 3 || res))
+        return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep: with a byte cell map only the plain 3D sweep exists, use "
+                                        "mgrt_smooth_pass");
     if (iters != 1 && iters != 2)
         return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep: iters must be 1 or 2, got %d", iters);
     hipStream_t hs = (hipStream_t)s;
@@ -642,6 +717,15 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
     using C = Cfg<R>;
     // strips of two rows halve the work a wave does per step (measured 25-30 % faster from 257^2 down)
     const bool small = latency_bound_level(*g);
+    if (g->cells) { // any domain: classes from the byte map (8-byte elements: strips of two rows, for registers)
+        if constexpr (sizeof(R) == 4) {
+            if (!small)
+                return iters == 1 ? launch<R, 1, 4, 8, 4, false, false, 1, true>(g, out, in, f, omega, zcount, hs)
+                                  : launch<R, 2, 4, 8, 2, false, false, 1, true>(g, out, in, f, omega, zcount, hs);
+        }
+        return iters == 1 ? launch<R, 1, 2, 8, 4, false, false, 1, true>(g, out, in, f, omega, zcount, hs)
+                          : launch<R, 2, 2, 8, 3, false, false, 1, true>(g, out, in, f, omega, zcount, hs);
+    }
     if (res) {
         // Strips of four rows only with 4-byte elements (registers).  Shapes chosen by timing whole
         // cycles: kernel-only timings on warm caches favour other shapes that lose in the cycle.

@@ -162,6 +162,41 @@ def test_fused_sweep_matches_oracle(dev, mgo, dt, shape):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", [(9, 11, 13), (5, 5, 5), (33, 17, 65), (20, 67, 129), (41, 130, 70), (37, 310, 322)],
+                         ids=lambda s: "x".join(map(str, s[::-1])))
+def test_fused_sweep_with_byte_map_matches_oracle(dev, mgo, dt, shape):
+    """The fused sweep on domains given as one byte per point (random inner / Neumann / Dirichlet / outer
+    cells, and a box spelled out as a map) against single-colour passes of the oracle."""
+    import torch
+    from multigrid_amd import _lib as L
+    rng = np.random.default_rng(abs(hash((shape, dt.__name__, "mapsweep"))) % 2**32)
+    maps = [mgo.box_cells(shape, (2, 3, 3, 2, 2, 3))]
+    if min(shape) >= 5:
+        maps.append(random_cells(mgo, rng, shape))
+    for cell in maps:
+        dcell = to_dev(cell, dev)
+        g = L.grid(shape, cells=dcell)
+        u = rng.standard_normal(shape).astype(dt)
+        f = rng.standard_normal(shape).astype(dt)
+        du, df = to_dev(u, dev), to_dev(f, dev)
+        for omega, iters, zc in ((1.0, 2, shape[0]), (0.8, 1, shape[0]), (1.0, 1, (shape[0] + 1) // 2), (0.9, 2, 1)):
+            ref = u.copy()
+            for _ in range(iters):
+                mgo.smooth_pass(cell, ref, f, dt(omega), 0, zc)
+                mgo.smooth_pass(cell, ref, f, dt(omega), 1, zc)
+            out = torch.full_like(du, 99.0)
+            L.smooth_sweep(g, out, du, df, omega, iters, zc)
+            assert bits_equal(out.cpu().numpy(), ref), (omega, iters, zc)
+        out = torch.full_like(du, 99.0)
+        L.smooth_sweep(g, out, None, df, 1.0, 2)  # a null input stands for zeros
+        ref = np.zeros_like(u)
+        for _ in range(2):
+            mgo.smooth_pass(cell, ref, f, dt(1.0), 0)
+            mgo.smooth_pass(cell, ref, f, dt(1.0), 1)
+        assert bits_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("shape", [(9, 11, 13), (5, 5, 5), (33, 17, 65), (20, 67, 129), (17, 130, 70), (40, 60, 58),
                                    (70, 140, 150)],
                          ids=lambda s: "x".join(map(str, s[::-1])))

@@ -67,7 +67,7 @@ def main():
                 is_vmem = op.startswith(("buffer_", "global_", "flat_", "scratch_"))
                 if asm:
                     if is_vmem:
-                        m = re.match(r"buffer_load_dword(?:x2)?\s+(\S+),", text_)
+                        m = re.match(r"buffer_load_(?:dword(?:x2)?|ubyte)\s+(\S+),", text_)
                         d = regs(m.group(1)) if m else set()
                         queue.append(d)
                         pending |= d
