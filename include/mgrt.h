@@ -73,6 +73,14 @@ typedef struct mgrt_grid {
     int y0, gny;    /* first global row held, global row count */
     const unsigned char *cells;
     int face[6];
+    /* What a Neumann cell is.  0: what the reference's kernels make of it -- a cell no kernel ever
+     * writes (`case CELL_NEUMANN: break;`, mg_1.cl:76-77,130-131).  1: an EXTENSION, not reference
+     * behaviour and not pinned by any reference result: the first-order condition the reference's
+     * set-up prepares data for (functionhandler.cpp:40-42,79-81 stores g*h there) and never applies:
+     * u_b = u_i + f_b with i the neighbour one step inside along the face's normal; residual
+     * f_b - (u_b - u_i); the restriction hands the coarse cell half of that (the spacing doubles).
+     * Analytic boxes only (cells == NULL); the single-colour kernels only. */
+    int neumann;
 } mgrt_grid;
 
 /* ---- runtime: replaces CLContextLoader (clcontextloader.cpp:29-80) and cl::Buffer / queue use
@@ -216,6 +224,9 @@ typedef struct mgrt_plan_desc {
     int no_fuse;      /* 1: smooth with one launch per colour pass (the unfused schedule) */
     int no_bottom;    /* 1: one launch per kernel on the coarsest levels too, instead of running them
                          as a single launch with every level held in LDS */
+    int neumann;      /* mgrt_grid.neumann for every level: 0 = the reference's frozen Neumann cells,
+                         1 = first-order Neumann condition (extension; implies the unfused schedule
+                         when a face is Neumann) */
 } mgrt_plan_desc;
 
 mgrt_status mgrt_plan_create(mgrt_plan **plan, const mgrt_plan_desc *desc, mgrt_stream s);

@@ -26,7 +26,7 @@ class Grid(C.Structure):
         ("dim", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
         ("pitch", C.c_int), ("slab", C.c_longlong),
         ("y0", C.c_int), ("gny", C.c_int),
-        ("cells", C.c_void_p), ("face", C.c_int * 6),
+        ("cells", C.c_void_p), ("face", C.c_int * 6), ("neumann", C.c_int),
     ]
 
 
@@ -35,7 +35,7 @@ class PlanDesc(C.Structure):
     _fields_ = [
         ("dim", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
         ("elem_size", C.c_int), ("face", C.c_int * 6), ("zfull", C.c_int), ("use_graph", C.c_int),
-        ("no_fuse", C.c_int), ("no_bottom", C.c_int),
+        ("no_fuse", C.c_int), ("no_bottom", C.c_int), ("neumann", C.c_int),
     ]
 
 
@@ -161,7 +161,7 @@ def init(device=0):
     _initialised = device
 
 
-def grid(shape, cells=None, faces=ALL_DIRICHLET, y0=0, gny=None, pitch=None, slab=None):
+def grid(shape, cells=None, faces=ALL_DIRICHLET, y0=0, gny=None, pitch=None, slab=None, neumann=0):
     """Build an mgrt_grid for arrays of numpy/torch shape (nz, ny, nx) or (ny, nx).
 
     `cells` is a device tensor (uint8, same shape) or None for the analytic box with `faces`.
@@ -179,6 +179,7 @@ def grid(shape, cells=None, faces=ALL_DIRICHLET, y0=0, gny=None, pitch=None, sla
     g.cells = None if cells is None else cells.data_ptr()
     g._keep = cells
     g.face = (C.c_int * 6)(*faces)
+    g.neumann = int(neumann)
     return g
 
 
@@ -312,7 +313,8 @@ def box_cells_host(shape, faces=ALL_DIRICHLET):
 class Plan:
     """mgrt_plan: pre-allocated hierarchy; iterate/mg/fmg of MultigridSolver{2,3}D on device arrays."""
 
-    def __init__(self, shape, dtype, faces=ALL_DIRICHLET, zfull=False, use_graph=False, no_fuse=False, no_bottom=False, stream=None):
+    def __init__(self, shape, dtype, faces=ALL_DIRICHLET, zfull=False, use_graph=False, no_fuse=False, no_bottom=False, neumann=0,
+                 stream=None):
         import torch
         d = PlanDesc()
         if len(shape) == 3:
@@ -325,6 +327,7 @@ class Plan:
         d.use_graph = int(use_graph)
         d.no_fuse = int(no_fuse)
         d.no_bottom = int(no_bottom)
+        d.neumann = int(neumann)
         self.shape, self.dtype = tuple(shape), dtype
         self._h = C.c_void_p()
         check(load().mgrt_plan_create(C.byref(self._h), C.byref(d), _stream(stream)))

@@ -78,6 +78,18 @@ mgrt_status bottom_cycle(int dim, int nlev, const int *nx, const int *ny, const 
 constexpr int kStaticPartials = 1 << 16;
 mgrt_status static_partials_setup(double **device_address);
 
+// Whether the grid asks for the first-order Neumann condition (an extension the fused kernels do not
+// carry) on a face that is Neumann.
+inline bool neumann_extension(const mgrt_grid *g)
+{
+    if (!g->neumann || g->cells)
+        return false;
+    for (int i = 0; i < (g->dim == 3 ? 6 : 4); ++i)
+        if (g->face[i] == MGRT_CELL_NEUMANN)
+            return true;
+    return false;
+}
+
 // The fused 3D sweeps address a z plane with 32-bit byte offsets and use offset 2^31 as the one the
 // hardware range check always drops, so a plane (rows x pitch) must stay below 2 GiB.
 inline bool plane_offsets_fit(const mgrt_grid *g, size_t elem)
@@ -90,7 +102,7 @@ inline bool plane_offsets_fit(const mgrt_grid *g, size_t elem)
 inline bool correct_sweep_3d_supported(const mgrt_grid *g, size_t elem, int iters)
 {
     return g->dim == 3 && elem == 4 && iters == 2 && !g->cells && g->y0 % 2 == 0 && g->nx % 2 == 1 && g->gny % 2 == 1 &&
-           g->nz % 2 == 1 && g->nz >= 5 && !latency_bound_level(*g) && plane_offsets_fit(g, elem);
+           g->nz % 2 == 1 && g->nz >= 5 && !latency_bound_level(*g) && plane_offsets_fit(g, elem) && !neumann_extension(g);
 }
 
 // out = S^iters(in) on a 2D analytic-box grid, iters 1 or 2 (mgrt_smooth2d.hip); in may be null.

@@ -60,6 +60,25 @@ __device__ __forceinline__ bool is_border(int t)
     return t == MGRT_CELL_DIRICHLET || t == MGRT_CELL_NEUMANN;
 }
 
+// Extension (mgrt_grid.neumann == 1, analytic box): element offset from a face cell to its neighbour
+// one step inside along the normal of the face the cell is counted to (same priority as cell_class).
+template <int DIM> __device__ __forceinline__ long long inward_offset(const mgrt_grid &g, int x, int y, int z)
+{
+    const int yg = y + g.y0;
+    if (DIM == 3) {
+        if (yg == 0) return g.pitch;
+        if (yg == g.gny - 1) return -(long long)g.pitch;
+        if (x == 0) return 1;
+        if (x == g.nx - 1) return -1;
+        if (z == 0) return g.slab;
+        return -g.slab;
+    }
+    if (x == 0) return 1;
+    if (x == g.nx - 1) return -1;
+    if (yg == 0) return g.pitch;
+    return -(long long)g.pitch;
+}
+
 // ---- smoother, 3D: one colour pass ------------------------------------------------------------
 // iteration_kernel + do_rbgauss + jacobi_iteration, mg_1.cl:29-43,56-104.  One thread owns one
 // (x,y) column of the active colour and marches it in ascending z: u_new[z-1] is carried in a
@@ -101,6 +120,14 @@ __global__ __launch_bounds__(kWave) void k_smooth3d_pass(mgrt_grid g, R *u, cons
             v.f = f[b];
         } else if (v.t == MGRT_CELL_DIRICHLET) {
             v.f = f[b];
+        } else if (v.t == MGRT_CELL_NEUMANN && g.neumann) {
+            // first-order condition: the neighbour inside.  Along z it is the plane above (its value
+            // before this pass) or below (after), which the march has in hand; in the plane it has the
+            // other colour and is read here.
+            v.f = f[b];
+            const long long in = inward_offset<3>(g, x, y, z);
+            if (in != s && in != -s)
+                v.xp = u[b + in];
         }
         return v;
     };
@@ -129,6 +156,11 @@ __global__ __launch_bounds__(kWave) void k_smooth3d_pass(mgrt_grid g, R *u, cons
                 } else if (c.t == MGRT_CELL_DIRICHLET) {
                     next = c.f;
                     u[col + s * z] = next;
+                } else if (c.t == MGRT_CELL_NEUMANN && g.neumann) {
+                    const long long in = inward_offset<3>(g, x, y, z);
+                    const R inside = in == s ? above : (in == -s ? below : c.xp);
+                    next = inside + c.f;
+                    u[col + s * z] = next;
                 }
                 below = next;
             }
@@ -156,6 +188,8 @@ __global__ __launch_bounds__(256) void k_smooth2d_pass(mgrt_grid g, R *u, const 
         u[b] = val * omega + (1.0 - omega) * u[b];
     } else if (t == MGRT_CELL_DIRICHLET) {
         u[b] = f[b];
+    } else if (t == MGRT_CELL_NEUMANN && g.neumann) {
+        u[b] = u[b + inward_offset<2>(g, x, y, 0)] + f[b];
     }
 }
 
@@ -236,6 +270,11 @@ __global__ __launch_bounds__(256) void k_residual(mgrt_grid g, R *r, const R *__
                     acc += (double)v * (double)v;
             } else if (t == MGRT_CELL_DIRICHLET) {
                 const R v = f[b] - uc;
+                r[b] = v;
+                if (NORM)
+                    acc += (double)v * (double)v;
+            } else if (t == MGRT_CELL_NEUMANN && g.neumann) {
+                const R v = f[b] - (uc - u[b + inward_offset<DIM>(g, x, y, z)]);
                 r[b] = v;
                 if (NORM)
                     acc += (double)v * (double)v;
@@ -376,7 +415,10 @@ __global__ __launch_bounds__(256) void k_restrict(mgrt_grid fg, mgrt_grid cg, R 
                      is_border(cell_class<DIM, MAP>(fg, x + 1, y + 1, z + 1));
     }
     if (border) {
-        rc[d] = c[0];
+        // extension: the coarse Neumann cell's equation spans twice the spacing and its correction is
+        // applied fourfold, so it takes half the fine residual
+        const bool halve = fg.neumann && !MAP && cell_class<DIM, false>(fg, x, y, z) == MGRT_CELL_NEUMANN;
+        rc[d] = halve ? (R)(0.5 * c[0]) : c[0];
     } else if (DIM == 3) {
         rc[d] = 1.0 / 64.0 * (c[s + p + 1] + c[s + p - 1] + c[s - p + 1] + c[s - p - 1] + c[-s + p + 1] +
                               c[-s + p - 1] + c[-s - p + 1] + c[-s - p - 1]) +
@@ -705,11 +747,12 @@ mgrt_status residual(const mgrt_grid *g, R *r, const R *u, const R *f, int zero_
         return MGRT_OK;
     }
     constexpr int ZC = 16;
-    const long long nthreads = g->dim == 3 ? (long long)((g->nx + 16 / (int)sizeof(R) - 1) / (16 / (int)sizeof(R))) * (yhi - ylo) : n;
+    const bool vec = g->dim == 3 && !g->neumann; // the 16-byte kernel; otherwise one thread per column, chunks of ZC planes
+    const long long nthreads = vec ? (long long)((g->nx + 16 / (int)sizeof(R) - 1) / (16 / (int)sizeof(R))) * (yhi - ylo) : n;
     const unsigned nbxy = blocks_for(nthreads, 256);
-    int zc3 = g->dim == 3 ? z_chunk(nbxy, g->nz, ZC) : 1;
+    int zc3 = vec ? z_chunk(nbxy, g->nz, ZC) : (g->dim == 3 ? ZC : 1);
     // with the norm every block leaves a partial sum: longer chunks keep their number within the scratch
-    while (norm2 && g->dim == 3 && zc3 < g->nz && (size_t)nbxy * blocks_for(g->nz, zc3) > (size_t)kMaxPartials)
+    while (norm2 && vec && zc3 < g->nz && (size_t)nbxy * blocks_for(g->nz, zc3) > (size_t)kMaxPartials)
         zc3 *= 2;
     dim3 grid(nbxy * (g->dim == 3 ? blocks_for(g->nz, zc3) : 1));
     const int nparts = (int)grid.x;
@@ -722,7 +765,9 @@ mgrt_status residual(const mgrt_grid *g, R *r, const R *u, const R *f, int zero_
 #define MGRT_LAUNCH_RES3(MAP, NORM)                                                                           \
     k_residual3d_v<R, MAP, NORM><<<grid, 256, 0, hs>>>(*g, r, u, f, zero_unwritten, parts, ylo, yhi, nbxy, zc3)
     const bool map = g->cells != nullptr, nrm = norm2 != nullptr;
-    if (g->dim == 3) {
+    if (g->dim == 3 && g->neumann) { // the extension lives in the plain kernel
+        if (nrm) MGRT_LAUNCH_RES(3, false, true); else MGRT_LAUNCH_RES(3, false, false);
+    } else if (g->dim == 3) {
         if (map) { if (nrm) MGRT_LAUNCH_RES3(true, true); else MGRT_LAUNCH_RES3(true, false); }
         else     { if (nrm) MGRT_LAUNCH_RES3(false, true); else MGRT_LAUNCH_RES3(false, false); }
     } else {

@@ -88,7 +88,7 @@ template <> struct K<double> {
 int bottom_from(const mgrt_plan *p)
 {
     const int n = (int)p->lv.size();
-    if (p->desc.no_bottom || p->desc.no_fuse)
+    if (p->desc.no_bottom || p->desc.no_fuse || neumann_extension(&p->lv[0].g))
         return n;
     int first = n;
     for (int l = n - 1; l >= 0; --l) {
@@ -119,7 +119,7 @@ mgrt_status run_bottom(mgrt_plan *p, int l, R *u, const R *u_in, const R *f, R o
 // kernel.
 bool sweepable(const mgrt_plan *p, const mgrt_grid &g)
 {
-    if (p->desc.no_fuse)
+    if (p->desc.no_fuse || neumann_extension(&g))
         return false;
     if (g.dim == 2)
         return g.cells == nullptr; // the 2D tile kernels know the analytic box only
@@ -341,6 +341,7 @@ mgrt_status mgrt_plan_create(mgrt_plan **plan, const mgrt_plan_desc *d, mgrt_str
     MGRT_REQUIRE(d->elem_size == 4 || d->elem_size == 8, "mgrt_plan_create: elem_size must be 4 or 8");
     const int nz0 = d->dim == 3 ? d->nz : 1;
     MGRT_REQUIRE(d->nx > 0 && d->ny > 0 && nz0 > 0, "mgrt_plan_create: extents must be positive");
+    MGRT_REQUIRE(d->neumann == 0 || d->neumann == 1, "mgrt_plan_create: neumann must be 0 or 1");
     for (int i = 0; i < 6; ++i)
         MGRT_REQUIRE(d->face[i] >= 1 && d->face[i] <= 3,
                      "mgrt_plan_create: face[%d] is not a class a face can have (outer, Dirichlet, Neumann)", i);
@@ -362,6 +363,7 @@ mgrt_status mgrt_plan_create(mgrt_plan **plan, const mgrt_plan_desc *d, mgrt_str
         L.g.y0 = 0;
         L.g.gny = ny;
         L.g.cells = nullptr;
+        L.g.neumann = d->neumann;
         for (int i = 0; i < 6; ++i)
             L.g.face[i] = d->face[i];
         L.n = (size_t)nx * ny * nz;
@@ -459,6 +461,8 @@ mgrt_status mgrt_plan_set_cells(mgrt_plan *p, int level, const unsigned char *ho
             }
     if (!L.cells)
         MGRT_HIP(hipMalloc((void **)&L.cells, L.n));
+    if (p->desc.neumann)
+        return fail(MGRT_E_UNSUPPORTED, "mgrt_plan_set_cells: the first-order Neumann condition needs the analytic box");
     MGRT_HIP(hipMemcpyAsync(L.cells, host_cells, L.n, hipMemcpyHostToDevice, p->stream));
     MGRT_HIP(hipStreamSynchronize(p->stream));
     L.g.cells = L.cells;

@@ -82,6 +82,10 @@ mgrt_status check_grid(const mgrt_grid *g, const char *who)
     MGRT_REQUIRE(g->y0 >= 0 && g->y0 + g->ny <= g->gny, "%s: rows [%d,%d) outside the global grid of %d rows",
                  who, g->y0, g->y0 + g->ny, g->gny);
     MGRT_REQUIRE(g->slab * (long long)g->nz < (1LL << 40), "%s: grid too large", who);
+    MGRT_REQUIRE(g->neumann == 0 || g->neumann == 1, "%s: neumann must be 0 or 1, got %d", who, g->neumann);
+    if (g->neumann && g->cells)
+        return fail(MGRT_E_UNSUPPORTED, "%s: the first-order Neumann condition needs the analytic box (a byte map carries "
+                                        "no normals)", who);
     if (!g->cells)
         for (int i = 0; i < 6; ++i)
             // an inner cell on a face would reach outside the arrays with its stencil

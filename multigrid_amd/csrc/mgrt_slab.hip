@@ -600,7 +600,7 @@ mgrt_status mgrt_slab_plan_create(mgrt_slab_plan **plan, const mgrt_slab_desc *d
         L.own0 = L.y0 - L.lo, L.own1 = L.y1 - L.lo;
         L.g.dim = 3, L.g.nx = nx, L.g.ny = L.nyl, L.g.nz = nz;
         L.g.pitch = nx, L.g.slab = (long long)nx * L.nyl;
-        L.g.y0 = L.lo, L.g.gny = ny, L.g.cells = nullptr;
+        L.g.y0 = L.lo, L.g.gny = ny, L.g.cells = nullptr, L.g.neumann = 0;
         for (int i = 0; i < 6; ++i)
             L.g.face[i] = d->face[i];
         L.n = (size_t)nx * L.nyl * nz;
@@ -641,7 +641,7 @@ mgrt_status mgrt_slab_plan_create(mgrt_slab_plan **plan, const mgrt_slab_desc *d
         if (e == hipSuccess) e = hipMemsetAsync(p->gather_in, 0, part, p->stream);
         mgrt_grid &c = p->cgrid;
         c.dim = 3, c.nx = p->cnx, c.ny = p->cny, c.nz = p->cnz, c.pitch = p->cnx, c.slab = (long long)p->cnx * p->cny;
-        c.y0 = 0, c.gny = p->cny, c.cells = nullptr;
+        c.y0 = 0, c.gny = p->cny, c.cells = nullptr, c.neumann = 0;
         for (int i = 0; i < 6; ++i)
             c.face[i] = d->face[i];
     }

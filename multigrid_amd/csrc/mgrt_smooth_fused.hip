@@ -708,6 +708,8 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
                                         "mgrt_smooth_pass");
     if (iters != 1 && iters != 2)
         return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep: iters must be 1 or 2, got %d", iters);
+    if (neumann_extension(g))
+        return fail(MGRT_E_UNSUPPORTED, "mgrt_smooth_sweep: the first-order Neumann condition is in mgrt_smooth_pass only");
     hipStream_t hs = (hipStream_t)s;
     if (g->dim != 3)
         return smooth_sweep_2d(g, nullptr, out, res, in, nullptr, f, omega, iters, hs);
@@ -766,6 +768,8 @@ mgrt_status correct_smooth_sweep(const mgrt_grid *fine, const mgrt_grid *coarse,
     MGRT_REQUIRE(zcount >= 0 && zcount <= fine->nz, "mgrt_correct_smooth_sweep: zcount %d outside [0,%d]", zcount, fine->nz);
     if (fine->cells || coarse->cells)
         return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: byte cell maps are not supported");
+    if (neumann_extension(fine))
+        return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: the first-order Neumann condition is in mgrt_smooth_pass only");
     if (iters != 1 && iters != 2)
         return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: iters must be 1 or 2, got %d", iters);
     // the coarse rows the fine rows interpolate from must be held, as for mgrt_correct (with an even
@@ -807,6 +811,8 @@ mgrt_status smooth_sweep_residual_restrict(const mgrt_grid *fine, const mgrt_gri
     MGRT_REQUIRE(zcount >= 0 && zcount <= fine->nz, "%s: zcount %d outside [0,%d]", who, zcount, fine->nz);
     if (fine->cells || coarse->cells)
         return fail(MGRT_E_UNSUPPORTED, "%s: byte cell maps are not supported", who);
+    if (neumann_extension(fine))
+        return fail(MGRT_E_UNSUPPORTED, "%s: the first-order Neumann condition is in mgrt_smooth_pass only", who);
     if (iters != 1 && iters != 2)
         return fail(MGRT_E_UNSUPPORTED, "%s: iters must be 1 or 2, got %d", who, iters);
     if (fine->dim != 2 || fine->nx % 2 == 0 || fine->ny % 2 == 0)
@@ -843,7 +849,7 @@ extern "C" mgrt_status mgrt_smooth_sweep_residual_restrict_f64(const mgrt_grid *
 
 extern "C" int mgrt_correct_smooth_sweep_supported(const mgrt_grid *fine, int elem_size, int iters)
 {
-    if (!fine || fine->cells || (iters != 1 && iters != 2) || (elem_size != 4 && elem_size != 8))
+    if (!fine || fine->cells || (iters != 1 && iters != 2) || (elem_size != 4 && elem_size != 8) || neumann_extension(fine))
         return 0;
     if (fine->dim == 2)
         return fine->nx % 2 == 1 && fine->gny % 2 == 1;

@@ -1,5 +1,10 @@
 """V-cycles on a 3D grid split into y-slabs, one slab per process (one process per GPU).
 
+This is the Python statement of the schedule that mgrt_slab_plan (libmgrt.so, csrc/mgrt_slab.hip) runs
+natively with RCCL and one graph per rank; bench.py uses that one.  This module stays as the form
+that runs on CPU tensors with a replaceable kernel set, which is how the multi-process CPU tests check
+the partitioning and the exchange schedule without a GPU.
+
 The fine levels of the hierarchy of MultigridSolver3D::iterate (multigridsolver3D.cpp:41-80) are
 cut along y: rank r owns the rows [B_r, B_r+1) of level 0 and the rows [B_r/2^l, B_r+1/2^l) of level
 l, so the owner of coarse row j is the owner of fine row 2j and restriction and interpolation need
@@ -168,12 +173,13 @@ class SlabCycle:
                                          (self.rank - 1, (a, a + HALO), (a - HALO, a))):
             if nb < 0 or nb >= self.world:
                 continue
-            key = (id(field), nb)
-            if key not in L.sendbuf:
+            # one staging pair per level and neighbour: every field of a level has the same halo shape,
+            # and an exchange has completed (wait below) before the next one reuses the pair
+            if nb not in L.sendbuf:
                 mk = lambda: torch.empty((L.local_shape[0], HALO, L.local_shape[2]), dtype=self.dtype,
                                          device="cpu" if self._stage else self.device)
-                L.sendbuf[key] = (mk(), mk())
-            sb, rb = L.sendbuf[key]
+                L.sendbuf[nb] = (mk(), mk())
+            sb, rb = L.sendbuf[nb]
             sb.copy_(field[:, send_rows[0]:send_rows[1], :])
             peer = dist.get_global_rank(self.group, nb) if self.group is not None else nb
             ops.append(dist.P2POp(dist.isend, sb, peer, self.group))

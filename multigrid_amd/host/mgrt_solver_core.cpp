@@ -25,6 +25,7 @@ mgrt_grid SolverCore::describe(const Dims &n)
     g.y0 = 0;
     g.gny = n.h;
     g.cells = 0;
+    g.neumann = 0; // Neumann cells as the reference treats them
     for (int i = 0; i < 6; ++i)
         g.face[i] = MGRT_CELL_DIRICHLET;
     m_bind(a, n);
@@ -101,6 +102,7 @@ mgrt_plan *SolverCore::planFor(const Dims &n)
     d.use_graph = useGraph ? 1 : 0;
     d.no_fuse = 0;
     d.no_bottom = 0;
+    d.neumann = 0;
     const mgrt_grid top = describe(n);
     for (int i = 0; i < 6; ++i)
         d.face[i] = top.face[i];

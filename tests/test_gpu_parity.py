@@ -647,6 +647,60 @@ def test_two_plans_on_two_streams_keep_their_norms_apart(dev):
     assert out[0] == serial[0] and out[1] == serial[1]
 
 
+@pytest.mark.parametrize("dim", [2, 3])
+def test_first_order_neumann_extension(dev, dim):
+    """neumann=1 is an extension, NOT reference behaviour, and no reference result pins it (the
+    reference never updates a Neumann cell, mg_1.cl:76-77): checked through what the mathematics
+    promises instead.  u = sin(pi x) e^y (times sin(pi z) in 3D) with du/dn given on the y faces and
+    Dirichlet values elsewhere: the cycles must converge, and the error against the analytic solution
+    must fall like h (the condition is first order)."""
+    import math
+    import torch
+    from multigrid_amd import _lib as L
+
+    def solve(n):
+        shape = (n,) * dim
+        ax = torch.arange(n, dtype=torch.float64, device=dev) / (n - 1)
+        h = 1.0 / (n - 1)
+        if dim == 3:
+            z, y, x = ax[:, None, None], ax[None, :, None], ax[None, None, :]
+            sol = torch.sin(math.pi * x) * torch.exp(y) * torch.sin(math.pi * z)
+            lap = (1.0 - 2.0 * math.pi ** 2) * sol
+            faces = (L.DIRICHLET, L.DIRICHLET, L.NEUMANN, L.NEUMANN, L.DIRICHLET, L.DIRICHLET)
+        else:
+            y, x = ax[:, None], ax[None, :]
+            sol = torch.sin(math.pi * x) * torch.exp(y)
+            lap = (1.0 - math.pi ** 2) * sol
+            faces = (L.DIRICHLET, L.DIRICHLET, L.NEUMANN, L.NEUMANN, L.DIRICHLET, L.DIRICHLET)
+        sol = sol.expand(shape).contiguous()
+        f = (lap * h * h).expand(shape).contiguous()
+        cells = torch.from_numpy(L.box_cells_host(shape, faces)).to(dev)
+        f = torch.where(cells == L.DIRICHLET, sol, f)
+        yy = y.expand(shape)
+        g = torch.where(yy < 0.5, -sol, sol)          # outward normal derivative on y = 0 and y = 1
+        f = torch.where(cells == L.NEUMANN, g * h, f).contiguous()
+        u = torch.zeros_like(f)
+        plan = L.Plan(shape, torch.float64, faces=faces, zfull=True, neumann=1)
+        hist = plan.vcycle(u, f, 1.0, 2, 2, 1, 14, history=True)
+        plan.close()
+        return hist, float((u - sol).abs().max())
+
+    h33, e33 = solve(33)
+    h65, e65 = solve(65)
+    for hist in (h33, h65):
+        assert hist[-1] < 1e-6 * hist[0], hist
+        assert all(b < 0.6 * a for a, b in zip(hist[2:8], hist[3:9])), hist  # a steady contraction per cycle
+    assert e65 < 0.05 and 1.5 < e33 / e65 < 2.8, (e33, e65)
+    # the default stays the reference's: the same problem with neumann=0 never touches the y faces
+    shape = (17,) * dim
+    f = torch.randn(shape, device=dev, dtype=torch.float64)
+    u = torch.zeros_like(f)
+    plan = L.Plan(shape, torch.float64, faces=(2, 2, 3, 3, 2, 2), zfull=True)
+    plan.vcycle(u, f, 1.0, 2, 2, 1, 2)
+    plan.close()
+    assert not u[..., 0, 1:-1].any() and not u[..., -1, 1:-1].any()
+
+
 def test_slab_rows_match_whole_grid(dev):
     """A y-slab with halo rows, addressed through y0/gny, reproduces the rows of the whole-grid
     result bit for bit (the property the multi-GPU decomposition rests on)."""
