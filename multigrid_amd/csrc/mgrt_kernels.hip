@@ -89,7 +89,9 @@ template <class R> struct PlaneVals {
     int t;
 };
 
-template <class R, bool MAP, int PF>
+// NEU: the first-order Neumann extension (mgrt_grid.neumann) is compiled in; the reference's kernels
+// are the instantiations without it.
+template <class R, bool MAP, int PF, bool NEU = false>
 __global__ __launch_bounds__(kWave) void k_smooth3d_pass(mgrt_grid g, R *u, const R *__restrict__ f,
                                                          R omega, int odd, int zcount, int ylo, int yhi)
 {
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(kWave) void k_smooth3d_pass(mgrt_grid g, R *u, cons
             v.f = f[b];
         } else if (v.t == MGRT_CELL_DIRICHLET) {
             v.f = f[b];
-        } else if (v.t == MGRT_CELL_NEUMANN && g.neumann) {
+        } else if (NEU && v.t == MGRT_CELL_NEUMANN) {
             // first-order condition: the neighbour inside.  Along z it is the plane above (its value
             // before this pass) or below (after), which the march has in hand; in the plane it has the
             // other colour and is read here.
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(kWave) void k_smooth3d_pass(mgrt_grid g, R *u, cons
                 } else if (c.t == MGRT_CELL_DIRICHLET) {
                     next = c.f;
                     u[col + s * z] = next;
-                } else if (c.t == MGRT_CELL_NEUMANN && g.neumann) {
+                } else if (NEU && c.t == MGRT_CELL_NEUMANN) {
                     const long long in = inward_offset<3>(g, x, y, z);
                     const R inside = in == s ? above : (in == -s ? below : c.xp);
                     next = inside + c.f;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(kWave) void k_smooth3d_pass(mgrt_grid g, R *u, cons
 }
 
 // ---- smoother, 2D: one colour pass (true red-black, mg_0.cl:29-40,52-98) ----------------------
-template <class R, bool MAP>
+template <class R, bool MAP, bool NEU = false>
 __global__ __launch_bounds__(256) void k_smooth2d_pass(mgrt_grid g, R *u, const R *__restrict__ f, R omega,
                                                        int odd, int ylo, int yhi)
 {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void k_smooth2d_pass(mgrt_grid g, R *u, const 
         u[b] = val * omega + (1.0 - omega) * u[b];
     } else if (t == MGRT_CELL_DIRICHLET) {
         u[b] = f[b];
-    } else if (t == MGRT_CELL_NEUMANN && g.neumann) {
+    } else if (NEU && t == MGRT_CELL_NEUMANN) {
         u[b] = u[b + inward_offset<2>(g, x, y, 0)] + f[b];
     }
 }
@@ -236,7 +238,7 @@ template <bool MAX> __global__ __launch_bounds__(256) void k_fold_partials(const
 // ---- residual (mg_1.cl:46-53,111-133, mg_0.cl:43-49,105-126) -----------------------------------
 // One thread per (x,y), marching a chunk of ZC planes with the three z values of its column held
 // in registers.  NORM adds sum(r*r) in double, one partial per block.
-template <class R, int DIM, bool MAP, bool NORM, int ZC>
+template <class R, int DIM, bool MAP, bool NORM, int ZC, bool NEU = false>
 __global__ __launch_bounds__(256) void k_residual(mgrt_grid g, R *r, const R *__restrict__ u,
                                                   const R *__restrict__ f, int zero_unwritten,
                                                   double *partials, int ylo, int yhi, unsigned nbxy)
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void k_residual(mgrt_grid g, R *r, const R *__
                 r[b] = v;
                 if (NORM)
                     acc += (double)v * (double)v;
-            } else if (t == MGRT_CELL_NEUMANN && g.neumann) {
+            } else if (NEU && t == MGRT_CELL_NEUMANN) {
                 const R v = f[b] - (uc - u[b + inward_offset<DIM>(g, x, y, z)]);
                 r[b] = v;
                 if (NORM)
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256) void k_residual3d_v(mgrt_grid g, R *r, const R
 // ---- full-weighting restriction (mg_1.cl:146-190, mg_0.cl:139-157) ----------------------------
 // One thread per coarse point.  `fine`/`coarse` may be y-slabs: coarse global row jg maps to fine
 // global row 2*jg.
-template <class R, int DIM, bool MAP>
+template <class R, int DIM, bool MAP, bool NEU = false>
 __global__ __launch_bounds__(256) void k_restrict(mgrt_grid fg, mgrt_grid cg, R *rc, const R *__restrict__ rf,
                                                   int cylo, int cyhi, unsigned nbxy)
 {
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256) void k_restrict(mgrt_grid fg, mgrt_grid cg, R 
     if (border) {
         // extension: the coarse Neumann cell's equation spans twice the spacing and its correction is
         // applied fourfold, so it takes half the fine residual
-        const bool halve = fg.neumann && !MAP && cell_class<DIM, false>(fg, x, y, z) == MGRT_CELL_NEUMANN;
+        const bool halve = NEU && cell_class<DIM, false>(fg, x, y, z) == MGRT_CELL_NEUMANN;
         rc[d] = halve ? (R)(0.5 * c[0]) : c[0];
     } else if (DIM == 3) {
         rc[d] = 1.0 / 64.0 * (c[s + p + 1] + c[s + p - 1] + c[s - p + 1] + c[s - p - 1] + c[-s + p + 1] +
@@ -697,12 +699,16 @@ mgrt_status smooth_pass(const mgrt_grid *g, R *u, const R *f, R omega, int odd, 
     hipStream_t hs = (hipStream_t)s;
     if (g->dim == 3) {
         constexpr int PF = 8;
-        if (g->cells)
+        if (neumann_extension(g))
+            k_smooth3d_pass<R, false, PF, true><<<blocks_for(n, kWave), kWave, 0, hs>>>(*g, u, f, omega, odd, zcount, ylo, yhi);
+        else if (g->cells)
             k_smooth3d_pass<R, true, PF><<<blocks_for(n, kWave), kWave, 0, hs>>>(*g, u, f, omega, odd, zcount, ylo, yhi);
         else
             k_smooth3d_pass<R, false, PF><<<blocks_for(n, kWave), kWave, 0, hs>>>(*g, u, f, omega, odd, zcount, ylo, yhi);
     } else {
-        if (g->cells)
+        if (neumann_extension(g))
+            k_smooth2d_pass<R, false, true><<<blocks_for(n, 256), 256, 0, hs>>>(*g, u, f, omega, odd, ylo, yhi);
+        else if (g->cells)
             k_smooth2d_pass<R, true><<<blocks_for(n, 256), 256, 0, hs>>>(*g, u, f, omega, odd, ylo, yhi);
         else
             k_smooth2d_pass<R, false><<<blocks_for(n, 256), 256, 0, hs>>>(*g, u, f, omega, odd, ylo, yhi);
@@ -747,7 +753,8 @@ mgrt_status residual(const mgrt_grid *g, R *r, const R *u, const R *f, int zero_
         return MGRT_OK;
     }
     constexpr int ZC = 16;
-    const bool vec = g->dim == 3 && !g->neumann; // the 16-byte kernel; otherwise one thread per column, chunks of ZC planes
+    const bool neu = neumann_extension(g);
+    const bool vec = g->dim == 3 && !neu; // the 16-byte kernel; otherwise one thread per column, chunks of ZC planes
     const long long nthreads = vec ? (long long)((g->nx + 16 / (int)sizeof(R) - 1) / (16 / (int)sizeof(R))) * (yhi - ylo) : n;
     const unsigned nbxy = blocks_for(nthreads, 256);
     int zc3 = vec ? z_chunk(nbxy, g->nz, ZC) : (g->dim == 3 ? ZC : 1);
@@ -762,11 +769,14 @@ mgrt_status residual(const mgrt_grid *g, R *r, const R *u, const R *f, int zero_
         if (mgrt_status st = partials_for(hs, &parts)) return st;
 #define MGRT_LAUNCH_RES(DIM, MAP, NORM)                                                                      \
     k_residual<R, DIM, MAP, NORM, ZC><<<grid, 256, 0, hs>>>(*g, r, u, f, zero_unwritten, parts, ylo, yhi, nbxy)
+#define MGRT_LAUNCH_RES_NEU(DIM, NORM)                                                                        \
+    k_residual<R, DIM, false, NORM, ZC, true><<<grid, 256, 0, hs>>>(*g, r, u, f, zero_unwritten, parts, ylo, yhi, nbxy)
 #define MGRT_LAUNCH_RES3(MAP, NORM)                                                                           \
     k_residual3d_v<R, MAP, NORM><<<grid, 256, 0, hs>>>(*g, r, u, f, zero_unwritten, parts, ylo, yhi, nbxy, zc3)
     const bool map = g->cells != nullptr, nrm = norm2 != nullptr;
-    if (g->dim == 3 && g->neumann) { // the extension lives in the plain kernel
-        if (nrm) MGRT_LAUNCH_RES(3, false, true); else MGRT_LAUNCH_RES(3, false, false);
+    if (neu) { // the extension lives in the plain kernel
+        if (g->dim == 3) { if (nrm) MGRT_LAUNCH_RES_NEU(3, true); else MGRT_LAUNCH_RES_NEU(3, false); }
+        else             { if (nrm) MGRT_LAUNCH_RES_NEU(2, true); else MGRT_LAUNCH_RES_NEU(2, false); }
     } else if (g->dim == 3) {
         if (map) { if (nrm) MGRT_LAUNCH_RES3(true, true); else MGRT_LAUNCH_RES3(true, false); }
         else     { if (nrm) MGRT_LAUNCH_RES3(false, true); else MGRT_LAUNCH_RES3(false, false); }
@@ -776,6 +786,7 @@ mgrt_status residual(const mgrt_grid *g, R *r, const R *u, const R *f, int zero_
     }
 #undef MGRT_LAUNCH_RES
 #undef MGRT_LAUNCH_RES3
+#undef MGRT_LAUNCH_RES_NEU
     MGRT_HIP(hipGetLastError());
     if (nrm)
         return fold<false>(parts, nparts, norm2, hs);
@@ -818,7 +829,10 @@ mgrt_status restrict_fw(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, c
     dim3 grid(nbxy * (unsigned)coarse->nz);
     hipStream_t hs = (hipStream_t)s;
     const bool map = fine->cells != nullptr;
-    if (fine->dim == 3) {
+    if (neumann_extension(fine)) {
+        if (fine->dim == 3) k_restrict<R, 3, false, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
+        else                k_restrict<R, 2, false, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
+    } else if (fine->dim == 3) {
         if (map) k_restrict<R, 3, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
         else     k_restrict<R, 3, false><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
     } else {

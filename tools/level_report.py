@@ -34,7 +34,7 @@ def main():
     # (on bandwidth-bound levels that sweep applies the correction itself: last template argument)
     def corrects(name):
         m = re.search(r"k_smooth3d_fused<([^>]*)>", name)
-        return bool(m) and m.group(1).split(",")[-1].strip() == "true"
+        return bool(m) and m.group(1).split(",")[7].strip() == "true"  # <R, ITERS, SR, NW, PD, OMEGA1, RES, COR, STAGES, MAP>
     last = max((i for i, r in enumerate(rows) if "k_interp3d_v" in r[2] or corrects(r[2])), default=None)
     if last is not None:
         end = last if corrects(rows[last][2]) else next(
@@ -52,7 +52,8 @@ def main():
             res, cor = targs[6] == "true", targs[7] == "true"
             if cor:
                 level -= 1
-            fam = "%ssweep x%s%s" % ("correct + " if cor else "", targs[1], " + residual" if res else "")
+            iters = int(targs[1]) * (int(targs[8]) if len(targs) > 8 else 1)  # iterations per stage x stages
+            fam = "%ssweep x%d%s" % ("correct + " if cor else "", iters, " + residual" if res else "")
             byts = (4 if res else 3) * pts[level] * w + (pts[level + 1] * w if cor else 0)
         elif k == "k_residual3d_v":
             if targs[-1] == "true":     # with the norm: the history between cycles, level 0

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Regenerates the artefacts kept under profiles/ on a GPU box, into gpurun_out/<tag>/: the bench line
 # alone and under rocprofv3 --kernel-trace --stats, the per-level report, the kernel microbenchmark,
-# separate FETCH_SIZE / WRITE_SIZE passes over it (-> pmc_traffic.json), the other configurations and
-# the solve to tolerance.  Every GPU step runs under its own time limit; the script stops at the
+# separate FETCH_SIZE / WRITE_SIZE passes over it (-> pmc_traffic.json), the other configurations, the
+# solve to tolerance, the one-GPU slab proxy, the bench lines of the other workloads and the 2- and
+# 8-rank rehearsals.  Every GPU step runs under its own time limit; the script stops at the
 # first failure.
 # Usage: tools/refresh_profiles.sh <tag>
 set -u
@@ -25,5 +26,12 @@ python3 tools/pmc_summary.py "$out/pmc" > "$out/pmc_fetch_write_kbench513.txt" |
 python3 tools/pmc_traffic.py "$out/pmc" 513 f32 "$out/pmc_traffic.json" || exit 1
 timeout -k 10 400 python3 tools/bench_configs.py > "$out/configs.txt" 2> "$out/configs.err" || exit 1
 timeout -k 10 400 python3 tools/solve_to_tol.py > "$out/solve_to_tolerance.txt" 2>&1 || exit 1
+timeout -k 10 300 python3 tools/slab_proxy.py > "$out/slab_proxy_513.txt" 2> "$out/slab_proxy.err" || exit 1
+for c in 2d257 2d4097mixed 3d257neumann 3d513f64 3d1025f64; do
+  timeout -k 10 400 python3 bench.py --config $c > "$out/bench_$c.json" 2> "$out/bench_$c.err" || exit 1
+done
+timeout -k 10 300 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu > "$out/rehearsal_gpus2.json" 2> "$out/rehearsal_gpus2.err" || exit 1
+timeout -k 10 400 python3 bench.py --gpus 8 --steps 3 --warmup 1 --no-cpu > "$out/rehearsal_gpus8.json" 2> "$out/rehearsal_gpus8.err" || exit 1
+timeout -k 10 60 tools/ubench/valu.bin > "$out/valu_rates.txt" 2>&1 || exit 1
 rm -rf "$out/trace"/*.db "$out/pmc"/*/*.db
 echo refreshed

@@ -16,8 +16,7 @@ L.init(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 513
 tol = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-8
 for dt in (torch.float64, torch.float32):
-    f, _ = make_problem(n, torch.device("cuda"))
-    f = f.to(dt)
+    f = make_problem((n, n, n), dt, (2,) * 6, torch.device("cuda"))
     u = torch.zeros_like(f)
     torch.cuda.synchronize()
     st = torch.cuda.Stream()
