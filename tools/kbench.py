@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--f64", action="store_true")
     ap.add_argument("--only", default="", help="substring filter on kernel names")
+    ap.add_argument("--dim", type=int, default=3, help="2: the 2D sweeps on an n x n grid")
     args = ap.parse_args()
     import torch
     from multigrid_amd import _lib as L
@@ -22,6 +23,8 @@ def main():
     n = args.n
     dt = torch.float64 if args.f64 else torch.float32
     w = 8 if args.f64 else 4
+    if args.dim == 2:
+        return bench2d(args, torch, L, dt, w)
     shape = (n, n, n)
     nc = (n + 1) // 2
     N = float(n) ** 3
@@ -67,6 +70,35 @@ def main():
         print("correct+smooth_sweep x2: %s" % err)
     timeit("prolong", lambda: L.prolong(g, gc, o, e), (N + Nc) * w)
     timeit("sumsq", lambda: L.sumsq(g, u, n2), N * w)
+
+
+def bench2d(args, torch, L, dt, w):
+    n = args.n
+    nc = (n + 1) // 2
+    N, Nc = float(n) ** 2, float(nc) ** 2
+    u = torch.randn((n, n), device="cuda", dtype=dt)
+    f = torch.randn((n, n), device="cuda", dtype=dt)
+    o = torch.empty_like(u)
+    e = torch.randn((nc, nc), device="cuda", dtype=dt)
+    rc = torch.empty_like(e)
+    g, gc = L.grid((n, n)), L.grid((nc, nc))
+    stream = torch.cuda.Stream()
+
+    def timeit(name, fn, nbytes):
+        with torch.cuda.stream(stream):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(args.reps):
+                fn()
+            e1.record(stream)
+            e1.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / args.reps
+        print("%-28s %9.1f us  %8.1f GB/s  (%4.1f%% of 8 TB/s)" % (name, t * 1e6, nbytes / t / 1e9, nbytes / t / 8e10))
+
+    timeit("2D smooth_sweep x2", lambda: L.smooth_sweep(g, o, u, f, 1.0, 2), 3 * N * w)
+    timeit("2D sweep+res+restrict x2", lambda: L.smooth_sweep_residual_restrict(g, gc, o, rc, u, f, 1.0, 2), (3 * N + Nc) * w)
+    timeit("2D correct+sweep x2", lambda: L.correct_smooth_sweep(g, gc, o, u, e, f, 1.0, 2), (3 * N + Nc) * w)
 
 
 if __name__ == "__main__":

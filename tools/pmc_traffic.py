@@ -42,7 +42,8 @@ def main():
                      "note": "FETCH_SIZE KB x 1024 x 2 (gfx950 half-count) + WRITE_SIZE KB x 1024, mean per launch"})
     try:
         with open(out) as fh:
-            old = [r for r in json.load(fh) if not (r["n"] == n and r["dtype"] == dtype)]
+            keys = {(r["kernel"], r["template"]) for r in rows}
+            old = [r for r in json.load(fh) if not (r["n"] == n and r["dtype"] == dtype and (r["kernel"], r["template"]) in keys)]
     except (OSError, ValueError):
         old = []
     with open(out, "w") as fh:

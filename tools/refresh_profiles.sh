@@ -24,6 +24,17 @@ timeout -k 10 200 python3 tools/kbench.py > "$out/kbench513.txt" 2>&1 || exit 1
 bash tools/pmc.sh "$out/pmc" fetch,write || exit 1
 python3 tools/pmc_summary.py "$out/pmc" > "$out/pmc_fetch_write_kbench513.txt" || exit 1
 python3 tools/pmc_traffic.py "$out/pmc" 513 f32 "$out/pmc_traffic.json" || exit 1
+# the dominant kernels of the other workloads: the same two counter passes at their sizes
+bash tools/pmc.sh "$out/pmc257" fetch,write --n 257 --only "smooth_sweep x2" || exit 1
+python3 tools/pmc_traffic.py "$out/pmc257" 257 f32 "$out/pmc_traffic.json" || exit 1
+bash tools/pmc.sh "$out/pmc513d" fetch,write --f64 --only "smooth_sweep x2" || exit 1
+python3 tools/pmc_traffic.py "$out/pmc513d" 513 f64 "$out/pmc_traffic.json" || exit 1
+bash tools/pmc.sh "$out/pmc1025d" fetch,write --f64 --n 1025 --only "smooth_sweep x2" || exit 1
+python3 tools/pmc_traffic.py "$out/pmc1025d" 1025 f64 "$out/pmc_traffic.json" || exit 1
+bash tools/pmc.sh "$out/pmc2d4097" fetch,write --dim 2 --n 4097 || exit 1
+python3 tools/pmc_traffic.py "$out/pmc2d4097" 4097 f32 "$out/pmc_traffic.json" || exit 1
+bash tools/pmc.sh "$out/pmc2d257" fetch,write --dim 2 --n 257 || exit 1
+python3 tools/pmc_traffic.py "$out/pmc2d257" 257 f32 "$out/pmc_traffic.json" || exit 1
 timeout -k 10 400 python3 tools/bench_configs.py > "$out/configs.txt" 2> "$out/configs.err" || exit 1
 timeout -k 10 400 python3 tools/solve_to_tol.py > "$out/solve_to_tolerance.txt" 2>&1 || exit 1
 timeout -k 10 300 python3 tools/slab_proxy.py > "$out/slab_proxy_513.txt" 2> "$out/slab_proxy.err" || exit 1
@@ -33,5 +44,5 @@ done
 timeout -k 10 300 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu > "$out/rehearsal_gpus2.json" 2> "$out/rehearsal_gpus2.err" || exit 1
 timeout -k 10 400 python3 bench.py --gpus 8 --steps 3 --warmup 1 --no-cpu > "$out/rehearsal_gpus8.json" 2> "$out/rehearsal_gpus8.err" || exit 1
 timeout -k 10 60 tools/ubench/valu.bin > "$out/valu_rates.txt" 2>&1 || exit 1
-rm -rf "$out/trace"/*.db "$out/pmc"/*/*.db
+rm -rf "$out/trace"/*.db "$out"/pmc*/*/*.db
 echo refreshed
