@@ -14,7 +14,9 @@ of that workload's dominant kernel and the CPU oracle timed on the same extents.
 For N > 1 there is one process per GPU (3d513 only): started by the caller with torch.distributed.run,
 or, when WORLD_SIZE is not set, started here as child processes before anything touches a GPU.  The
 grid is cut into N slabs along y (mgrt_slab_plan of libmgrt.so: halos over RCCL, a whole cycle of a
-rank replayed from one hipGraph); total work is fixed: strong scaling.  On a box with fewer than N GPUs
+rank replayed from one hipGraph); total work is fixed: strong scaling.  After that timed region a second
+one, reported beside the line's value as "grown_grid", runs the same plan on 513 x (512 N + 1) x 513 points
+(every rank keeps 512 rows: weak scaling; --no-weak skips it).  On a box with fewer than N GPUs
 the ranks share the devices and the halos go through host callbacks over gloo (a rehearsal of the path,
 marked as such in the output, not a measurement).
 """
@@ -166,6 +168,8 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 with fewer than N GPUs: ranks share the devices, gloo with host staging; checks that "
                          "the path runs, the number is not a measurement (chosen by itself when GPUs are short)")
+    ap.add_argument("--no-weak", action="store_true",
+                    help="N > 1: skip the second, separately timed leg on a grid that grows with the ranks")
     ap.add_argument("--crossover", type=int, default=129 ** 3,
                     help="N > 1: levels with at most this many points are solved whole on every rank")
     args = ap.parse_args()
@@ -214,56 +218,78 @@ def main():
             dist.all_reduce(sync.cpu())
             torch.cuda.synchronize()
 
-    layout = None
+    layout, weak = None, None
     if world > 1:
         # mgrt_slab_plan: this rank's slab, halos over RCCL on the plan's stream, a cycle per graph launch.
         # torch.distributed (gloo) only hands the RCCL id round and closes the timed region.
-        def make_plan(transport, rid):
-            return _lib.SlabPlan(shape, tdt, transport=transport, rank=rank, nranks=world, rccl_id=rid, faces=faces,
-                                 zfull=True, crossover=args.crossover, use_graph=not args.no_graph)
-        transport_note = "host callbacks over gloo (rehearsal)"
-        cyc = None
-        if not rehearse:
-            # every rank must end up on the same transport: agree on whether RCCL came up everywhere
-            err = ""
-            try:
-                box = [_lib.rccl_unique_id() if rank == 0 else None]
-            except _lib.MgrtError as e:
-                box, err = [None], str(e)
-            dist.broadcast_object_list(box, src=0)
-            if box[0] is not None:
+        use_rccl = [not rehearse]
+        note = ["host callbacks over gloo (rehearsal)"]
+
+        def make_plan(shp):
+            def create(transport, rid):
+                return _lib.SlabPlan(shp, tdt, transport=transport, rank=rank, nranks=world, rccl_id=rid, faces=faces,
+                                     zfull=True, crossover=args.crossover, use_graph=not args.no_graph)
+            cyc = None
+            if use_rccl[0]:
+                # every rank must end up on the same transport: agree on whether RCCL came up everywhere
+                err = ""
                 try:
-                    cyc = make_plan("rccl", box[0])
+                    box = [_lib.rccl_unique_id() if rank == 0 else None]
                 except _lib.MgrtError as e:
-                    err = str(e)
-            bad = torch.tensor([0 if cyc is not None else 1])
-            dist.all_reduce(bad)
-            if bad.item():
-                if cyc is not None:
-                    cyc.close()
-                    cyc = None
-                transport_note = "host callbacks over gloo: RCCL did not come up on %d rank(s)%s" % (
-                    bad.item(), " (" + err + ")" if err else "")
-            else:
-                transport_note = "RCCL"
-        if cyc is None:
-            cyc = make_plan(_lib.GlooTransport(), None)
-        fl, ul = cyc.scatter(f), cyc.scatter(u)
+                    box, err = [None], str(e)
+                dist.broadcast_object_list(box, src=0)
+                if box[0] is not None:
+                    try:
+                        cyc = create("rccl", box[0])
+                    except _lib.MgrtError as e:
+                        err = str(e)
+                bad = torch.tensor([0 if cyc is not None else 1])
+                dist.all_reduce(bad)
+                if bad.item():
+                    if cyc is not None:
+                        cyc.close()
+                        cyc = None
+                    use_rccl[0] = False
+                    note[0] = "host callbacks over gloo: RCCL did not come up on %d rank(s)%s" % (
+                        bad.item(), " (" + err + ")" if err else "")
+                else:
+                    note[0] = "RCCL"
+            return cyc if cyc is not None else create(_lib.GlooTransport(), None)
+
+        def run_slabs(shp, fw, uw):
+            cyc = make_plan(shp)
+            fl, ul = cyc.scatter(fw), cyc.scatter(uw)
+            del fw, uw
+            ra = cyc.vcycle(ul, fl, ncycles=0, history=True)[0]
+            cyc.vcycle(ul, fl, 1.0, 2, 2, 1, args.warmup)
+            barrier()
+            t0 = time.perf_counter()
+            cyc.vcycle(ul, fl, 1.0, 2, 2, 1, args.steps)
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rb = cyc.vcycle(ul, fl, ncycles=0, history=True)[0]
+            lo, hi, a, b = cyc.rows()
+            lay = {"rank0_rows_owned": b - a, "halo_rows": 4, "levels_cut": cyc.distributed_levels,
+                   "whole_on_every_rank_from_points": args.crossover, "cycle_in_one_graph": cyc.uses_graph,
+                   "transport": note[0]}
+            cyc.close()
+            return t.item(), ra, rb, lay
+
+        dt, r0, r1, layout = run_slabs(shape, f, u)
         del f, u
-        r0 = cyc.vcycle(ul, fl, ncycles=0, history=True)[0]
-        cyc.vcycle(ul, fl, 1.0, 2, 2, 1, args.warmup)
-        barrier()
-        t0 = time.perf_counter()
-        cyc.vcycle(ul, fl, 1.0, 2, 2, 1, args.steps)
-        barrier()
-        dt = time.perf_counter() - t0
-        r1 = cyc.vcycle(ul, fl, ncycles=0, history=True)[0]
-        lo, hi, a, b = cyc.rows()
-        layout = {"rank0_rows_owned": b - a, "halo_rows": 4, "levels_cut": cyc.distributed_levels,
-                  "whole_on_every_rank_from_points": args.crossover, "cycle_in_one_graph": cyc.uses_graph,
-                  "transport": transport_note}
-        cyc.close()
-        del fl, ul
+        if not args.no_weak:
+            # The other question, beside the line's own value: a grid that grows with the ranks, so that every
+            # rank keeps the rows of a one-GPU problem and only exchanges and gathered levels come on top.
+            wshape = (shape[0], 512 * world + 1, shape[2])
+            fw = make_problem(wshape, tdt, faces, dev)
+            torch.cuda.synchronize()
+            wdt, wr0, wr1, wlay = run_slabs(wshape, fw, torch.zeros_like(fw))
+            del fw
+            wdof = float(wshape[0]) * wshape[1] * wshape[2]
+            weak = {"workload": "3D Poisson %dx%dx%d (z,y,x), %s, V(2,2): %d rows a rank" % (wshape + (dtname, 512)),
+                    "value": wdof * args.steps / wdt, "unit": "DOF/s", "ms_per_step": wdt / args.steps * 1e3,
+                    "scaling": "weak", "layout": wlay, "residual_before": wr0, "residual_after_warmup_and_steps": wr1}
         f = make_problem(shape, tdt, faces, dev)
         u = torch.zeros_like(f)
         torch.cuda.synchronize()
@@ -318,11 +344,6 @@ def main():
         e1.synchronize()
         t_kernel = e0.elapsed_time(e1) * 1e-3 / reps
 
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-
     if rank == 0:
         achieved = alg_bytes / t_kernel / 1e9
         traffic = pmc_traffic(kernel[0], n, dtname, fields)
@@ -350,6 +371,7 @@ def main():
                        "layout": layout,
                        "residual_before": r0, "residual_after_warmup_and_steps": r1},
             "vcycles_per_s": args.steps / dt,
+            **({"grown_grid": weak} if weak else {}),
             "cycle_gbs_unfused_model": cyc_bytes * args.steps / dt / 1e9,
             "roofline": {"bound": "hbm", "kernel": "%s: %s, finest level" % kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

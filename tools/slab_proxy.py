@@ -4,7 +4,11 @@ N-way y-slab split (mgrt_slab_plan with the stand-alone transport: packing, unpa
 the same size as the halos stay on the device, nothing crosses a wire).  T_N below is therefore a
 lower bound of the N-GPU cycle time, and T_1 / (N * T_N) an upper bound of the parallel efficiency.
 
-usage: tools/slab_proxy.py [--n 513] [--f64] [--crossover 2146689] [--cycles 20]"""
+--weak times the other question: a grid that grows with the ranks (n x (512 N + 1) x n, every rank
+keeps about 512 rows), where the share of a rank stays a full one-GPU problem and only the exchanges and
+the gathered coarse levels come on top.
+
+usage: tools/slab_proxy.py [--n 513] [--f64] [--crossover 2146689] [--cycles 20] [--weak]"""
 import argparse
 import json
 import os
@@ -21,6 +25,7 @@ def main():
     ap.add_argument("--crossover", type=int, default=129 ** 3)
     ap.add_argument("--cycles", type=int, default=20)
     ap.add_argument("--ranks", default="1,2,4,8")
+    ap.add_argument("--weak", action="store_true", help="the grid grows with the ranks: n x (512 N + 1) x n")
     args = ap.parse_args()
     import torch
     from multigrid_amd import _lib as L
@@ -28,10 +33,10 @@ def main():
     L.init(0)
     dt = torch.float64 if args.f64 else torch.float32
     n = args.n
-    shape = (n, n, n)
     rows = []
     t1 = None
     for world in [int(x) for x in args.ranks.split(",")]:
+        shape = (n, 512 * world + 1, n) if args.weak else (n, n, n)
         for graph in (True, False):
             plan = L.SlabPlan(shape, dt, transport=None, rank=world // 2, nranks=world, crossover=args.crossover,
                               use_graph=graph)
@@ -53,8 +58,8 @@ def main():
                 t1 = t
             rows.append({"ranks": world, "graph": graph, "rows_owned": b - a, "rows_stored": hi - lo, "levels_cut": nd,
                          "ms_per_cycle": round(t * 1e3, 4),
-                         "speedup_bound": round(t1 / t, 3) if t1 else None,
-                         "efficiency_bound": round(t1 / t / world, 3) if t1 else None})
+                         "speedup_bound": round(t1 / t * (world if args.weak else 1), 3) if t1 else None,
+                         "efficiency_bound": round(t1 / t / (1 if args.weak else world), 3) if t1 else None})
             print(json.dumps(rows[-1]), flush=True)
 
 
