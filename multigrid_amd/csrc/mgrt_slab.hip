@@ -286,6 +286,7 @@ mgrt_status gather_coarse(mgrt_slab_plan *p)
 template <class R> struct K;
 template <> struct K<float> {
     static constexpr auto sweep = mgrt_smooth_sweep_f32;
+    static constexpr auto sweep_res = mgrt_smooth_sweep_residual_f32;
     static constexpr auto correct_sweep = mgrt_correct_smooth_sweep_f32;
     static constexpr auto residual = mgrt_residual_f32;
     static constexpr auto restrict_ = mgrt_restrict_f32;
@@ -294,6 +295,7 @@ template <> struct K<float> {
 };
 template <> struct K<double> {
     static constexpr auto sweep = mgrt_smooth_sweep_f64;
+    static constexpr auto sweep_res = mgrt_smooth_sweep_residual_f64;
     static constexpr auto correct_sweep = mgrt_correct_smooth_sweep_f64;
     static constexpr auto residual = mgrt_residual_f64;
     static constexpr auto restrict_ = mgrt_restrict_f64;
@@ -306,9 +308,12 @@ int zcount_of(const mgrt_slab_plan *p, const mgrt_slab_plan::Level &L)
     return p->desc.zfull ? L.nz : L.nz / 2 + L.nz % 2; // multigridsolver3D.cpp:121
 }
 
-// `a` iterations as sweeps of two (and one odd one), each preceded by the exchange its halo needs
+// `a` iterations as sweeps of two (and one odd one), each preceded by the exchange its halo needs.
+// With `res` the last sweep also leaves f - A u there, good on the rows whose stencil stays inside the
+// owned rows (the rows next to them were smoothed from halo rows that are stale by then).
 template <class R>
-mgrt_status smooth(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, R *&cur, R *&alt, const R *f, R omega, int a, bool &halo_valid)
+mgrt_status smooth(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, R *&cur, R *&alt, const R *f, R omega, int a, bool &halo_valid,
+                   R *res = nullptr)
 {
     mgrt_stream s = (mgrt_stream)p->stream;
     for (int left = a; left > 0;) {
@@ -316,7 +321,10 @@ mgrt_status smooth(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, R *&cur, R *&alt
         if (!halo_valid)
             if (mgrt_status st = exchange(p, L, cur))
                 return st;
-        if (mgrt_status st = K<R>::sweep(&L.g, alt, cur, f, omega, n, zcount_of(p, L), s))
+        if (res && left == n) {
+            if (mgrt_status st = K<R>::sweep_res(&L.g, alt, res, cur, f, omega, n, zcount_of(p, L), s))
+                return st;
+        } else if (mgrt_status st = K<R>::sweep(&L.g, alt, cur, f, omega, n, zcount_of(p, L), s))
             return st;
         R *t = cur;
         cur = alt, alt = t;
@@ -334,7 +342,10 @@ mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1,
     mgrt_slab_plan::Level &L = p->lv[l];
     mgrt_stream s = (mgrt_stream)p->stream;
     R *cur = u, *alt = (R *)L.work;
-    if (mgrt_status st = smooth<R>(p, L, cur, alt, f, omega, a1, halo_valid))
+    // As on one GPU, the last pre-smoothing sweep of a bandwidth-bound level in single precision carries
+    // the residual pass along (slabs too thin for strips of four rows: measured slower than the two kernels).
+    const bool res_in_sweep = a1 > 0 && v > 0 && sizeof(R) == 4 && !latency_bound_level(L.g) && L.own1 - L.own0 > 2;
+    if (mgrt_status st = smooth<R>(p, L, cur, alt, f, omega, a1, halo_valid, res_in_sweep ? (R *)L.r : nullptr))
         return st;
     const bool last = l + 1 == p->ndist;
     for (int it = 0; it < v; ++it) {
@@ -342,7 +353,17 @@ mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1,
         // whose stencil stays inside the owned rows are formed while the halo of the unknown travels,
         // the two rows at either end afterwards.
         const int rlo = L.y0 > 0 ? L.own0 - 1 : L.own0, rhi = L.y1 < L.gny ? L.own1 + 1 : L.own1;
-        if (!halo_valid && L.own1 - L.own0 > 2) {
+        if (res_in_sweep && it == 0) {
+            // the sweep left the rows in between; the two at either end need the neighbours' rows
+            if (mgrt_status st = exchange(p, L, cur))
+                return st;
+            halo_valid = true;
+            const int ilo = L.own0 + 1, ihi = L.own1 - 1;
+            if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, rlo, ilo, s))
+                return st;
+            if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, ihi, rhi, s))
+                return st;
+        } else if (!halo_valid && L.own1 - L.own0 > 2) {
             if (mgrt_status st = exchange_begin(p, L, cur))
                 return st;
             const int ilo = L.own0 + 1, ihi = L.own1 - 1;
