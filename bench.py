@@ -18,7 +18,9 @@ rank replayed from one hipGraph); total work is fixed: strong scaling.  After th
 one, reported beside the line's value as "grown_grid", runs the same plan on 513 x (512 N + 1) x 513 points
 (every rank keeps 512 rows: weak scaling; --no-weak skips it).  On a box with fewer than N GPUs
 the ranks share the devices and the halos go through host callbacks over gloo (a rehearsal of the path,
-marked as such in the output, not a measurement).
+marked as such in the output, not a measurement).  Each rank does its work in a child process and watches
+it: when an attempt fails or stops making progress on any rank, all ranks go on to the next one (RCCL with
+the cycle in a graph, RCCL with direct launches, host callbacks), and the line says which attempts failed.
 """
 import argparse
 import json
@@ -156,6 +158,74 @@ def spawn_ranks(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+ATTEMPTS = (
+    # what a rank's worker is asked to do, most wanted first; a later one is tried when an earlier one
+    # fails or stops making progress (a collective that never returns cannot be left from inside)
+    ("RCCL, cycle in one graph", []),
+    ("RCCL, direct launches", ["--no-graph"]),
+    ("host callbacks over gloo", ["--no-graph", "--transport", "gloo"]),
+)
+PHASE_LIMIT_S = {"start": 420.0}  # the first import of torch on a fresh box pages the image in
+PHASE_LIMIT_DEFAULT_S = float(os.environ.get("MGRT_BENCH_PHASE_LIMIT_S", "150"))
+
+
+def supervise(argv):
+    """One rank of N > 1: run the work in a child (this process never touches a GPU), watch the phases it
+    reports, and move every rank on to the next, more conservative attempt when one fails or hangs.  All
+    ranks walk the same list: a hang in a collective stops all of them, and a rank whose worker died early
+    waits in the next attempt's rendezvous for the others.  Only the output of the attempt that finished is
+    passed on."""
+    import tempfile
+    rank = int(os.environ.get("RANK", "0"))
+    failures = []
+    for k, (what, extra) in enumerate(ATTEMPTS):
+        with tempfile.TemporaryDirectory(prefix="mgrt_bench_") as tmp:
+            phase_file = os.path.join(tmp, "phase")
+            open(phase_file, "w").close()
+            env = dict(os.environ, MGRT_BENCH_PHASE_FILE=phase_file, MGRT_BENCH_ATTEMPT=str(k),
+                       MGRT_BENCH_EARLIER="; ".join(failures))
+            with open(os.path.join(tmp, "out"), "w+") as out:
+                child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker"] + argv + extra,
+                                         env=env, stdout=out)
+                phase, since, why = "start", time.monotonic(), None
+                while child.poll() is None:
+                    time.sleep(0.25)
+                    now = open(phase_file).read().split()
+                    if now and now[-1] != phase:
+                        phase, since = now[-1], time.monotonic()
+                    if phase != "done" and time.monotonic() - since > PHASE_LIMIT_S.get(phase, PHASE_LIMIT_DEFAULT_S):
+                        why = "no progress for %.0f s in phase '%s'" % (time.monotonic() - since, phase)
+                        child.kill()
+                        child.wait()
+                        break
+                now = open(phase_file).read().split()
+                if now and now[-1] == "done":  # the result is out; how the process ended after that is not the bench's business
+                    out.seek(0)
+                    sys.stdout.write(out.read())
+                    sys.stdout.flush()
+                    return 0
+                why = why or "worker left with status %s in phase '%s'" % (child.returncode, now[-1] if now else "start")
+        failures.append("%s: %s" % (what, why))
+        print("bench.py rank %d: %s; %s" % (rank, failures[-1], "trying: " + ATTEMPTS[k + 1][0] if k + 1 < len(ATTEMPTS)
+                                             else "giving up"), file=sys.stderr, flush=True)
+    return 1
+
+
+def phase(name):
+    path = os.environ.get("MGRT_BENCH_PHASE_FILE")
+    if path:
+        with open(path, "a") as fh:
+            fh.write(name + "\n")
+    # rehearsing the supervisor: MGRT_BENCH_TEST_FAIL="attempt:rank:phase-prefix:exit|hang,..."
+    for item in filter(None, os.environ.get("MGRT_BENCH_TEST_FAIL", "").split(",")):
+        a, r, ph, how = item.split(":")
+        if a == os.environ.get("MGRT_BENCH_ATTEMPT") and r == os.environ.get("RANK") and name.startswith(ph):
+            if how == "exit":
+                os._exit(3)
+            while True:
+                time.sleep(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,13 +242,19 @@ def main():
                     help="N > 1: skip the second, separately timed leg on a grid that grows with the ranks")
     ap.add_argument("--crossover", type=int, default=129 ** 3,
                     help="N > 1: levels with at most this many points are solved whole on every rank")
+    ap.add_argument("--transport", choices=("rccl", "gloo"), default="rccl",
+                    help="N > 1: how halos travel (gloo: blocking host callbacks; chosen by itself when RCCL does not come up)")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
+    if args.gpus > 1 and not args.worker:
+        sys.exit(supervise(sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
     from multigrid_amd import _lib
+    phase("imported")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -196,8 +272,16 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("gloo")
+        # every attempt of the supervisor gets a rendezvous of its own on the launcher's store
+        attempt = os.environ.get("MGRT_BENCH_ATTEMPT", "0")
+        if os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True":
+            base = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, False)
+        else:
+            base = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + int(attempt), world, rank == 0)
+        dist.init_process_group("gloo", store=dist.PrefixStore("mgrt_bench_attempt_" + attempt, base), rank=rank,
+                                world_size=world)
     _lib.init(local)
+    phase("setup")
 
     shape, dtname, faces, _, workload = CONFIGS[args.config]
     if args.n:
@@ -222,8 +306,8 @@ def main():
     if world > 1:
         # mgrt_slab_plan: this rank's slab, halos over RCCL on the plan's stream, a cycle per graph launch.
         # torch.distributed (gloo) only hands the RCCL id round and closes the timed region.
-        use_rccl = [not rehearse]
-        note = ["host callbacks over gloo (rehearsal)"]
+        use_rccl = [not rehearse and args.transport == "rccl"]
+        note = ["host callbacks over gloo" + (" (rehearsal)" if rehearse else "")]
 
         def make_plan(shp):
             def create(transport, rid):
@@ -257,15 +341,19 @@ def main():
             return cyc if cyc is not None else create(_lib.GlooTransport(), None)
 
         def run_slabs(shp, fw, uw):
+            phase("plan-%d-rows" % shp[1])
             cyc = make_plan(shp)
             fl, ul = cyc.scatter(fw), cyc.scatter(uw)
             del fw, uw
             ra = cyc.vcycle(ul, fl, ncycles=0, history=True)[0]
+            phase("warmup-%d-rows" % shp[1])
             cyc.vcycle(ul, fl, 1.0, 2, 2, 1, args.warmup)
             barrier()
+            phase("timing-%d-rows" % shp[1])
             t0 = time.perf_counter()
             cyc.vcycle(ul, fl, 1.0, 2, 2, 1, args.steps)
             barrier()
+            phase("timed-%d-rows" % shp[1])
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rb = cyc.vcycle(ul, fl, ncycles=0, history=True)[0]
@@ -294,6 +382,7 @@ def main():
         u = torch.zeros_like(f)
         torch.cuda.synchronize()
 
+    phase("kernel")
     with torch.cuda.stream(stream):
         if world == 1:
             plan = _lib.Plan(shape, tdt, faces=faces, zfull=True, use_graph=not args.no_graph)
@@ -382,8 +471,12 @@ def main():
             del f, u, work
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(args.config if not args.n else args.config)
+        if os.environ.get("MGRT_BENCH_EARLIER"):
+            out["config"]["attempts_that_failed"] = os.environ["MGRT_BENCH_EARLIER"]
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
+        phase("done")
         dist.destroy_process_group()
 
 
