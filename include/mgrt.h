@@ -293,6 +293,11 @@ typedef struct mgrt_slab_plan mgrt_slab_plan;
 
 /* a fresh ncclUniqueId (ncclGetUniqueId); one rank makes it, every rank passes it in mgrt_transport */
 mgrt_status mgrt_rccl_unique_id(unsigned char id[128]);
+/* the RCCL operations a slab plan uses, on a communicator of one rank (so that a single GPU can run it):
+ * send/receive with itself, all-gather and all-reduce, queued directly and replayed from a captured graph,
+ * results checked.  MGRT_E_UNSUPPORTED where RCCL is absent, MGRT_E_TRANSPORT with the finding otherwise.
+ * No counterpart in the reference. */
+mgrt_status mgrt_rccl_selftest(mgrt_stream s);
 /* collective over the transport's ranks; `s` must be a stream of its own (not NULL) */
 mgrt_status mgrt_slab_plan_create(mgrt_slab_plan **plan, const mgrt_slab_desc *desc, const mgrt_transport *transport,
                                   mgrt_stream s);

@@ -69,7 +69,7 @@ _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "u
             "stream_create", "stream_destroy", "sync", "zero", "box_cells_host",
             "plan_create", "plan_destroy", "plan_levels", "plan_level_dims", "plan_set_cells",
             "plan_vcycle", "plan_fmg", "correct_smooth_sweep_supported", "sumsq_noalloc_f32",
-            "rccl_unique_id", "slab_plan_create", "slab_plan_destroy", "slab_plan_distributed_levels",
+            "rccl_unique_id", "rccl_selftest", "slab_plan_create", "slab_plan_destroy", "slab_plan_distributed_levels",
             "slab_plan_uses_graph", "slab_plan_rows", "slab_plan_vcycle"]
 SYMBOLS = ["mgrt_" + n for n in _RUNTIME] + ["mgrt_%s_%s" % (k, s) for k in _KERNELS for s in ("f32", "f64")]
 
@@ -102,6 +102,7 @@ def load():
         "plan_fmg": [p, p, p, d, i, i, i, i],
         "sumsq_noalloc_f32": [G, p, p, i, i, p],
         "rccl_unique_id": [p],
+        "rccl_selftest": [p],
         "slab_plan_create": [C.POINTER(p), C.POINTER(SlabDesc), C.POINTER(Transport), p],
         "slab_plan_destroy": [p],
         "slab_plan_rows": [p, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)],
@@ -377,6 +378,11 @@ def rccl_unique_id():
     buf = (C.c_ubyte * 128)()
     check(load().mgrt_rccl_unique_id(buf))
     return bytes(buf)
+
+
+def rccl_selftest(stream):
+    """The RCCL operations of a slab plan on a one-rank communicator, direct and from a graph (raises on a finding)."""
+    check(load().mgrt_rccl_selftest(C.c_void_p(stream.cuda_stream)))
 
 
 class GlooTransport:

@@ -563,6 +563,88 @@ mgrt_status mgrt_rccl_unique_id(unsigned char id[128])
     return MGRT_OK;
 }
 
+// The RCCL operations of a slab plan on a communicator of one rank: a send/receive pair with itself in
+// one group, an all-gather and an all-reduce, queued directly and then replayed from a captured graph,
+// each result checked.  What a single GPU can tell about the binding (symbols, the id passed by value,
+// the enum values) and about capturing RCCL work on the installed runtime.
+mgrt_status mgrt_rccl_selftest(mgrt_stream s)
+{
+    if (mgrt_status st = require_init()) return st;
+    MGRT_REQUIRE(s != nullptr, "mgrt_rccl_selftest: a stream of its own is required (the default stream cannot be captured)");
+    Rccl *nc = nullptr;
+    if (mgrt_status st = rccl(&nc)) return st;
+    hipStream_t hs = (hipStream_t)s;
+    constexpr size_t kBytes = 4096;
+    mgrt_rccl_id_by_value id;
+    MGRT_NCCL(nc->GetUniqueId(&id));
+    void *comm = nullptr;
+    MGRT_NCCL(nc->CommInitRank(&comm, 1, id, 0));
+    unsigned char *a = nullptr, *b = nullptr, *c = nullptr;
+    double *d = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    auto queue = [&]() -> mgrt_status {
+        MGRT_NCCL(nc->GroupStart());
+        MGRT_NCCL(nc->Send(a, kBytes, kNcclChar, 0, comm, hs));
+        MGRT_NCCL(nc->Recv(b, kBytes, kNcclChar, 0, comm, hs));
+        MGRT_NCCL(nc->GroupEnd());
+        MGRT_NCCL(nc->AllGather(b, c, kBytes, kNcclChar, comm, hs));
+        MGRT_NCCL(nc->AllReduce(d, d + 1, 1, kNcclDouble, kNcclSum, comm, hs));
+        return MGRT_OK;
+    };
+    auto check = [&](int fill, double value, const char *how) -> mgrt_status {
+        unsigned char back[kBytes];
+        double sum = 0;
+        MGRT_HIP(hipMemcpyAsync(back, c, kBytes, hipMemcpyDeviceToHost, hs));
+        MGRT_HIP(hipMemcpyAsync(&sum, d + 1, sizeof sum, hipMemcpyDeviceToHost, hs));
+        MGRT_HIP(hipStreamSynchronize(hs));
+        for (size_t i = 0; i < kBytes; ++i)
+            if (back[i] != (unsigned char)fill)
+                return fail(MGRT_E_TRANSPORT, "mgrt_rccl_selftest (%s): byte %zu came back as %d, not %d", how, i, back[i], fill);
+        if (sum != value)
+            return fail(MGRT_E_TRANSPORT, "mgrt_rccl_selftest (%s): all-reduce gave %g, not %g", how, sum, value);
+        return MGRT_OK;
+    };
+    auto fill = [&](int byte, double value) -> mgrt_status {
+        MGRT_HIP(hipMemsetAsync(a, byte, kBytes, hs));
+        MGRT_HIP(hipMemsetAsync(b, 0, kBytes, hs));
+        MGRT_HIP(hipMemsetAsync(c, 0, kBytes, hs));
+        MGRT_HIP(hipMemcpyAsync(d, &value, sizeof value, hipMemcpyHostToDevice, hs));
+        MGRT_HIP(hipMemsetAsync(d + 1, 0, sizeof(double), hs));
+        MGRT_HIP(hipStreamSynchronize(hs)); // `value` is on this frame
+        return MGRT_OK;
+    };
+    auto run = [&]() -> mgrt_status {
+        MGRT_HIP(hipMalloc((void **)&a, kBytes));
+        MGRT_HIP(hipMalloc((void **)&b, kBytes));
+        MGRT_HIP(hipMalloc((void **)&c, kBytes));
+        MGRT_HIP(hipMalloc((void **)&d, 2 * sizeof(double)));
+        if (mgrt_status st = fill(0x5a, 1.25)) return st;
+        if (mgrt_status st = queue()) return st;
+        if (mgrt_status st = check(0x5a, 1.25, "direct")) return st;
+        if (mgrt_status st = fill(0xa5, -3.5)) return st;
+        MGRT_HIP(hipStreamBeginCapture(hs, hipStreamCaptureModeThreadLocal));
+        const mgrt_status st = queue();
+        const hipError_t e = hipStreamEndCapture(hs, &graph);
+        if (st != MGRT_OK) return st;
+        MGRT_HIP(e);
+        MGRT_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        MGRT_HIP(hipGraphLaunch(exec, hs));
+        if (mgrt_status st2 = check(0xa5, -3.5, "replayed from a graph")) return st2;
+        if (mgrt_status st2 = fill(0x3c, 7.0)) return st2;
+        MGRT_HIP(hipGraphLaunch(exec, hs));
+        return check(0x3c, 7.0, "replayed a second time");
+    };
+    const mgrt_status st = run();
+    (void)hipStreamSynchronize(hs);
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    for (void *q : {(void *)a, (void *)b, (void *)c, (void *)d})
+        (void)hipFree(q);
+    (void)nc->CommDestroy(comm);
+    return st;
+}
+
 mgrt_status mgrt_slab_plan_create(mgrt_slab_plan **plan, const mgrt_slab_desc *d, const mgrt_transport *t, mgrt_stream s)
 {
     if (mgrt_status st = require_init()) return st;
