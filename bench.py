@@ -47,13 +47,17 @@ CONFIGS = {
 }
 
 
-def make_problem(shape, dtype, faces, device):
+def make_problem(shape, dtype, faces, device, rows=None):
     """The reference's test problems sampled as discretize_func does (functionhandler.cpp:25-45,64-84):
     3D tridimF1/tridimS1 (programstate.cpp:114-122), 2D sinfunc2/sinfunc2sol (:84-94).  Interior
-    F*h*h in `real`, Dirichlet cells the exact solution, Neumann cells the solution times h."""
+    F*h*h in `real`, Dirichlet cells the exact solution, Neumann cells the solution times h.
+    rows = (lo, hi): only those y rows of the 3D field (a rank's slab), the same values."""
     import math
     import torch
     ax = [(torch.arange(n, device=device, dtype=dtype) / (n - 1)).double() for n in shape]
+    ylo, yhi = rows if rows else (0, shape[-2])
+    if rows:
+        ax[1] = ax[1][ylo:yhi]
     if len(shape) == 3:
         s = [torch.sin(math.pi * a) for a in ax]
         sol = s[0][:, None, None] * s[1][None, :, None] * s[2][None, None, :]
@@ -64,6 +68,7 @@ def make_problem(shape, dtype, faces, device):
         rhs = -26 * 26 * math.pi ** 2 * torch.sin(26 * math.pi * x) - 50 * 50 * math.pi ** 2 * torch.cos(50 * math.pi * y) \
             - math.pi ** 2 * torch.sin(math.pi * x)
         rhs = rhs.expand(shape)
+    ny = shape[-2]
     dh = torch.tensor(1.0 / (shape[-1] - 1), dtype=dtype, device=device)
     f = rhs.to(dtype) * dh * dh
     sol = sol.to(dtype)
@@ -72,6 +77,8 @@ def make_problem(shape, dtype, faces, device):
     order = [(nd - 3, 4), (nd - 3, 5), (nd - 1, 0), (nd - 1, 1), (nd - 2, 2), (nd - 2, 3)] if nd == 3 else \
         [(0, 2), (0, 3), (1, 0), (1, 1)]
     for axis, face in order:
+        if axis == nd - 2 and (ylo > 0 if face % 2 == 0 else yhi < ny):
+            continue  # that face of the grid is not among these rows
         idx = [slice(None)] * nd
         idx[axis] = 0 if face % 2 == 0 else -1
         idx = tuple(idx)
@@ -201,7 +208,8 @@ def supervise(argv):
                 now = open(phase_file).read().split()
                 if now and now[-1] == "done":  # the result is out; how the process ended after that is not the bench's business
                     out.seek(0)
-                    sys.stdout.write(out.read())
+                    for line in out:  # the result line to stdout; what libraries printed there goes to stderr
+                        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
                     sys.stdout.flush()
                     return 0
                 why = why or "worker left with status %s in phase '%s'" % (child.returncode, now[-1] if now else "start")
@@ -267,8 +275,8 @@ def main():
     rehearse = args.rehearse or (world > 1 and ndev < world)
     if rehearse:
         local = local % ndev
-    if world > 1 and args.config != "3d513":
-        sys.exit("bench.py: the multi-GPU path runs the 3d513 workload")
+    if world > 1 and (len(CONFIGS[args.config][0]) != 3 or set(CONFIGS[args.config][2]) != {D_}):
+        sys.exit("bench.py: the multi-GPU path runs the 3D Dirichlet boxes (3d513, 3d513f64, 3d1025f64)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -290,8 +298,9 @@ def main():
     tdt = torch.float32 if dtname == "f32" else torch.float64
     w = 4 if dtname == "f32" else 8
     n = shape[-1]
-    f = make_problem(shape, tdt, faces, dev)
-    u = torch.zeros_like(f)
+    if world == 1:
+        f = make_problem(shape, tdt, faces, dev)
+        u = torch.zeros_like(f)
     stream = torch.cuda.Stream()
     sync = torch.zeros(1, device=dev)
     torch.cuda.synchronize()  # the fields were produced on the default stream
@@ -340,11 +349,12 @@ def main():
                     note[0] = "RCCL"
             return cyc if cyc is not None else create(_lib.GlooTransport(), None)
 
-        def run_slabs(shp, fw, uw):
+        def run_slabs(shp):
             phase("plan-%d-rows" % shp[1])
             cyc = make_plan(shp)
-            fl, ul = cyc.scatter(fw), cyc.scatter(uw)
-            del fw, uw
+            fl = make_problem(shp, tdt, faces, dev, rows=cyc.rows()[:2])  # this rank's rows, halo included
+            ul = torch.zeros_like(fl)
+            torch.cuda.synchronize()
             ra = cyc.vcycle(ul, fl, ncycles=0, history=True)[0]
             phase("warmup-%d-rows" % shp[1])
             cyc.vcycle(ul, fl, 1.0, 2, 2, 1, args.warmup)
@@ -364,23 +374,25 @@ def main():
             cyc.close()
             return t.item(), ra, rb, lay
 
-        dt, r0, r1, layout = run_slabs(shape, f, u)
-        del f, u
+        dt, r0, r1, layout = run_slabs(shape)
         if not args.no_weak:
             # The other question, beside the line's own value: a grid that grows with the ranks, so that every
             # rank keeps the rows of a one-GPU problem and only exchanges and gathered levels come on top.
-            wshape = (shape[0], 512 * world + 1, shape[2])
-            fw = make_problem(wshape, tdt, faces, dev)
-            torch.cuda.synchronize()
-            wdt, wr0, wr1, wlay = run_slabs(wshape, fw, torch.zeros_like(fw))
-            del fw
+            wshape = (shape[0], (shape[1] - 1) * world + 1, shape[2])
+            need = 6.0 * wshape[0] * (shape[1] + 7) * wshape[2] * w * -(-world // ndev)  # fields of the ranks of one device
+            have = torch.cuda.get_device_properties(local).total_memory
+        if not args.no_weak and need > 0.8 * have:
+            weak = {"skipped": "the ranks sharing a device would need %.0f GB of its %.0f GB" % (need / 1e9, have / 1e9)}
+        elif not args.no_weak:
+            wdt, wr0, wr1, wlay = run_slabs(wshape)
             wdof = float(wshape[0]) * wshape[1] * wshape[2]
-            weak = {"workload": "3D Poisson %dx%dx%d (z,y,x), %s, V(2,2): %d rows a rank" % (wshape + (dtname, 512)),
+            weak = {"workload": "3D Poisson %dx%dx%d (z,y,x), %s, V(2,2): %d rows a rank" % (wshape + (dtname, shape[1] - 1)),
                     "value": wdof * args.steps / wdt, "unit": "DOF/s", "ms_per_step": wdt / args.steps * 1e3,
                     "scaling": "weak", "layout": wlay, "residual_before": wr0, "residual_after_warmup_and_steps": wr1}
-        f = make_problem(shape, tdt, faces, dev)
-        u = torch.zeros_like(f)
-        torch.cuda.synchronize()
+        if rank == 0:  # for the kernel timed alone below
+            f = make_problem(shape, tdt, faces, dev)
+            u = torch.zeros_like(f)
+            torch.cuda.synchronize()
 
     phase("kernel")
     with torch.cuda.stream(stream):
@@ -396,42 +408,43 @@ def main():
             r1 = plan.vcycle(u, f, ncycles=0, history=True)[0]
             plan.close()
 
-        # The dominant kernel of the workload: the pre-smoothing launch of the finest level, the longest
-        # of the cycle, timed alone with events on the stream it runs on.
-        g = _lib.grid(shape, faces=faces)
-        dof = 1.0
-        for s in shape:
-            dof *= s
-        work = torch.empty_like(u)
-        if len(shape) == 2:
-            cshape = tuple((s + 1) // 2 for s in shape)
-            gc = _lib.grid(cshape, faces=faces)
-            rc = torch.empty(cshape, dtype=tdt, device=dev)
-            launch = lambda a, b: _lib.smooth_sweep_residual_restrict(g, gc, a, rc, b, f, 1.0, 2)
-            alg_bytes = (3.0 * dof + float(rc.numel())) * w
-            kernel = ("k_smooth2d_cols", "2D sweep of 2 red-black iterations that also writes the restricted residual")
-            fields = {0: "float" if w == 4 else "double", 1: "2", 5: "2"}
-        elif w == 4 and shape[1] * shape[2] > 300 * 300:
-            resid = torch.empty_like(u)
-            launch = lambda a, b: _lib.smooth_sweep_residual(g, a, resid, b, f, 1.0, 2)
-            alg_bytes = 4.0 * dof * w  # read u, read f, write the smoothed field, write the residual
-            kernel = ("k_smooth3d_fused", "3D sweep of 2 red-black iterations with the residual pass")
-            fields = {0: "float", 1: "2", 5: "true", 6: "true", 7: "false"}
-        else:
-            launch = lambda a, b: _lib.smooth_sweep(g, a, b, f, 1.0, 2)
-            alg_bytes = 3.0 * dof * w  # read u, read f, write the smoothed field
-            kernel = ("k_smooth3d_fused", "3D sweep of 2 red-black iterations")
-            fields = {0: "float" if w == 4 else "double", 1: "2", 5: "true", 6: "false", 7: "false"}
-        reps = 20 if dof < 6e8 else 6
-        launch(work, u)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for i in range(reps // 2):
+        if rank == 0:
+            # The dominant kernel of the workload: the pre-smoothing launch of the finest level, the longest
+            # of the cycle, timed alone with events on the stream it runs on.
+            g = _lib.grid(shape, faces=faces)
+            dof = 1.0
+            for s in shape:
+                dof *= s
+            work = torch.empty_like(u)
+            if len(shape) == 2:
+                cshape = tuple((s + 1) // 2 for s in shape)
+                gc = _lib.grid(cshape, faces=faces)
+                rc = torch.empty(cshape, dtype=tdt, device=dev)
+                launch = lambda a, b: _lib.smooth_sweep_residual_restrict(g, gc, a, rc, b, f, 1.0, 2)
+                alg_bytes = (3.0 * dof + float(rc.numel())) * w
+                kernel = ("k_smooth2d_cols", "2D sweep of 2 red-black iterations that also writes the restricted residual")
+                fields = {0: "float" if w == 4 else "double", 1: "2", 5: "2"}
+            elif w == 4 and shape[1] * shape[2] > 300 * 300:
+                resid = torch.empty_like(u)
+                launch = lambda a, b: _lib.smooth_sweep_residual(g, a, resid, b, f, 1.0, 2)
+                alg_bytes = 4.0 * dof * w  # read u, read f, write the smoothed field, write the residual
+                kernel = ("k_smooth3d_fused", "3D sweep of 2 red-black iterations with the residual pass")
+                fields = {0: "float", 1: "2", 5: "true", 6: "true", 7: "false"}
+            else:
+                launch = lambda a, b: _lib.smooth_sweep(g, a, b, f, 1.0, 2)
+                alg_bytes = 3.0 * dof * w  # read u, read f, write the smoothed field
+                kernel = ("k_smooth3d_fused", "3D sweep of 2 red-black iterations")
+                fields = {0: "float" if w == 4 else "double", 1: "2", 5: "true", 6: "false", 7: "false"}
+            reps = 20 if dof < 6e8 else 6
             launch(work, u)
-            launch(u, work)
-        e1.record(stream)
-        e1.synchronize()
-        t_kernel = e0.elapsed_time(e1) * 1e-3 / reps
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for i in range(reps // 2):
+                launch(work, u)
+                launch(u, work)
+            e1.record(stream)
+            e1.synchronize()
+            t_kernel = e0.elapsed_time(e1) * 1e-3 / reps
 
     if rank == 0:
         achieved = alg_bytes / t_kernel / 1e9

@@ -245,3 +245,17 @@ def test_bitmap_roundtrip_2d(tmp_path):
     assert raw[54:62] == bytes([0, 0, 0, 0, 1, 1, 1, 1])
     px = np.frombuffer(raw, np.uint8, offset=off).reshape(33, 36)
     assert px[:, 33:].max() == 0 and px.max() == 255
+
+
+def test_bench_problem_of_a_slab_equals_the_rows_of_the_whole():
+    # bench.py lets every rank sample its own rows; they must be the rows of the one-GPU problem
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    for faces in ((2,) * 6, (2, 2, 3, 3, 2, 2)):
+        for dt in (torch.float32, torch.float64):
+            whole = bench.make_problem((9, 17, 9), dt, faces, torch.device("cpu"))
+            for lo, hi in ((0, 7), (4, 13), (9, 17), (0, 17)):
+                part = bench.make_problem((9, 17, 9), dt, faces, torch.device("cpu"), rows=(lo, hi))
+                assert torch.equal(part, whole[:, lo:hi, :])
