@@ -16,7 +16,8 @@ or, when WORLD_SIZE is not set, started here as child processes before anything 
 grid is cut into N slabs along y (mgrt_slab_plan of libmgrt.so: halos over RCCL, a whole cycle of a
 rank replayed from one hipGraph); total work is fixed: strong scaling.  After that timed region a second
 one, reported beside the line's value as "grown_grid", runs the same plan on 513 x (512 N + 1) x 513 points
-(every rank keeps 512 rows: weak scaling; --no-weak skips it).  On a box with fewer than N GPUs
+(every rank keeps 512 rows: weak scaling), and a third the 1025^3 double-precision grid cut N ways,
+reported as "fixed_grid_1025_f64" (--no-weak skips both).  On a box with fewer than N GPUs
 the ranks share the devices and the halos go through host callbacks over gloo (a rehearsal of the path,
 marked as such in the output, not a measurement).  Each rank does its work in a child process and watches
 it: when an attempt fails or stops making progress on any rank, all ranks go on to the next one (RCCL with
@@ -247,7 +248,8 @@ def main():
                     help="N > 1 with fewer than N GPUs: ranks share the devices, gloo with host staging; checks that "
                          "the path runs, the number is not a measurement (chosen by itself when GPUs are short)")
     ap.add_argument("--no-weak", action="store_true",
-                    help="N > 1: skip the second, separately timed leg on a grid that grows with the ranks")
+                    help="N > 1: skip the separately timed legs beside the line's own (the grid that grows with the "
+                         "ranks, the 1025^3 double-precision grid)")
     ap.add_argument("--crossover", type=int, default=129 ** 3,
                     help="N > 1: levels with at most this many points are solved whole on every rank")
     ap.add_argument("--transport", choices=("rccl", "gloo"), default="rccl",
@@ -311,14 +313,14 @@ def main():
             dist.all_reduce(sync.cpu())
             torch.cuda.synchronize()
 
-    layout, weak = None, None
+    layout, weak, big = None, None, None
     if world > 1:
         # mgrt_slab_plan: this rank's slab, halos over RCCL on the plan's stream, a cycle per graph launch.
         # torch.distributed (gloo) only hands the RCCL id round and closes the timed region.
         use_rccl = [not rehearse and args.transport == "rccl"]
         note = ["host callbacks over gloo" + (" (rehearsal)" if rehearse else "")]
 
-        def make_plan(shp):
+        def make_plan(shp, tdt):
             def create(transport, rid):
                 return _lib.SlabPlan(shp, tdt, transport=transport, rank=rank, nranks=world, rccl_id=rid, faces=faces,
                                      zfull=True, crossover=args.crossover, use_graph=not args.no_graph)
@@ -349,9 +351,9 @@ def main():
                     note[0] = "RCCL"
             return cyc if cyc is not None else create(_lib.GlooTransport(), None)
 
-        def run_slabs(shp):
+        def run_slabs(shp, tdt=tdt):
             phase("plan-%d-rows" % shp[1])
-            cyc = make_plan(shp)
+            cyc = make_plan(shp, tdt)
             fl = make_problem(shp, tdt, faces, dev, rows=cyc.rows()[:2])  # this rank's rows, halo included
             ul = torch.zeros_like(fl)
             torch.cuda.synchronize()
@@ -389,6 +391,18 @@ def main():
             weak = {"workload": "3D Poisson %dx%dx%d (z,y,x), %s, V(2,2): %d rows a rank" % (wshape + (dtname, shape[1] - 1)),
                     "value": wdof * args.steps / wdt, "unit": "DOF/s", "ms_per_step": wdt / args.steps * 1e3,
                     "scaling": "weak", "layout": wlay, "residual_before": wr0, "residual_after_warmup_and_steps": wr1}
+        if args.config == "3d513" and not args.no_weak:
+            # the configuration named for a whole node, 1025^3 in double precision, cut the same way (fixed grid)
+            bshape = CONFIGS["3d1025f64"][0]
+            need = 6.0 * bshape[0] * ((bshape[1] - 1) // world + 9) * bshape[2] * 8 * -(-world // ndev)
+            if need > 0.8 * torch.cuda.get_device_properties(local).total_memory:
+                big = {"skipped": "the ranks sharing a device would need %.0f GB" % (need / 1e9)}
+            else:
+                bdt, br0, br1, blay = run_slabs(bshape, torch.float64)
+                bdof = float(bshape[0]) * bshape[1] * bshape[2]
+                big = {"workload": CONFIGS["3d1025f64"][4] + ", f64, V(2,2)", "value": bdof * args.steps / bdt, "unit": "DOF/s",
+                       "ms_per_step": bdt / args.steps * 1e3, "scaling": "strong", "layout": blay,
+                       "residual_before": br0, "residual_after_warmup_and_steps": br1}
         if rank == 0:  # for the kernel timed alone below
             f = make_problem(shape, tdt, faces, dev)
             u = torch.zeros_like(f)
@@ -474,6 +488,7 @@ def main():
                        "residual_before": r0, "residual_after_warmup_and_steps": r1},
             "vcycles_per_s": args.steps / dt,
             **({"grown_grid": weak} if weak else {}),
+            **({"fixed_grid_1025_f64": big} if big else {}),
             "cycle_gbs_unfused_model": cyc_bytes * args.steps / dt / 1e9,
             "roofline": {"bound": "hbm", "kernel": "%s: %s, finest level" % kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
