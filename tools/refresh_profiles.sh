@@ -38,6 +38,8 @@ python3 tools/pmc_traffic.py "$out/pmc2d257" 257 f32 "$out/pmc_traffic.json" || 
 timeout -k 10 400 python3 tools/bench_configs.py > "$out/configs.txt" 2> "$out/configs.err" || exit 1
 timeout -k 10 400 python3 tools/solve_to_tol.py > "$out/solve_to_tolerance.txt" 2>&1 || exit 1
 timeout -k 10 300 python3 tools/slab_proxy.py > "$out/slab_proxy_513.txt" 2> "$out/slab_proxy.err" || exit 1
+timeout -k 10 300 python3 tools/slab_proxy.py --weak > "$out/slab_proxy_weak.txt" 2>> "$out/slab_proxy.err" || exit 1
+timeout -k 10 600 python3 tools/slab_proxy.py --n 1025 --f64 --cycles 4 > "$out/slab_proxy_1025f64.txt" 2>> "$out/slab_proxy.err" || exit 1
 for c in 2d257 2d4097mixed 3d257neumann 3d513f64 3d1025f64; do
   timeout -k 10 400 python3 bench.py --config $c > "$out/bench_$c.json" 2> "$out/bench_$c.err" || exit 1
 done
