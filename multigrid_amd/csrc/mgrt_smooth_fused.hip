@@ -718,7 +718,16 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
                                         "offsets of this kernel, use mgrt_smooth_pass");
     using C = Cfg<R>;
     // strips of two rows halve the work a wave does per step (measured 25-30 % faster from 257^2 down)
-    const bool small = latency_bound_level(*g);
+    bool small = latency_bound_level(*g);
+    if (!small && !g->cells && !res) {
+        // A wide but short slab (the share of one of many ranks) can give too few tiles of four-row strips
+        // for the CUs while the tiles of two-row strips still fit in one round: take those
+        // (1025 x 136 rows in double precision: 114 against 171 tiles, 12 % off the cycle of that slab).
+        const int h = 2 * iters, ntx = (g->nx + kWave - 2 * h - 1) / (kWave - 2 * h);
+        const int rows_small = (iters == 1 ? 16 : sizeof(R) == 4 ? 16 : 24) - 2 * h;
+        const int big = ntx * ((g->ny + 32 - 2 * h - 1) / (32 - 2 * h)), thin = ntx * ((g->ny + rows_small - 1) / rows_small);
+        small = 16 * big <= 9 * runtime().num_cu && thin <= runtime().num_cu;
+    }
     if (g->cells) { // any domain: classes from the byte map (8-byte elements: strips of two rows, for registers)
         if constexpr (sizeof(R) == 4) {
             if (!small)

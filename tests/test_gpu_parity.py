@@ -135,7 +135,8 @@ def test_kernels_match_oracle(dev, mgo, dt, shape):
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("shape", [(9, 11, 13), (5, 5, 5), (3, 3, 3), (33, 17, 65), (20, 67, 129), (17, 130, 70),
-                                   (40, 60, 58), (6, 25, 121)],
+                                   (40, 60, 58), (6, 25, 121),
+                                   (7, 97, 1025)],  # wide and short: too few tiles of four-row strips for the CUs
                          ids=lambda s: "x".join(map(str, s[::-1])))
 def test_fused_sweep_matches_oracle(dev, mgo, dt, shape):
     """out = S^iters(in) in one z-march against 2*iters single-colour passes of the oracle."""
