@@ -313,6 +313,10 @@ mgrt_status mgrt_slab_plan_rows(const mgrt_slab_plan *plan, int *lo, int *hi, in
  * of u are exchanged here.  res_hist as in mgrt_plan_vcycle, norms over the whole grid. */
 mgrt_status mgrt_slab_plan_vcycle(mgrt_slab_plan *plan, void *u, const void *f, double omega, int a1, int a2, int v,
                                   int ncycles, double *res_hist);
+/* fmg(f, omega, a1, a2, v, iters) of multigridsolver3D.cpp:82-109 on this rank's rows: u_out is written (halo
+ * rows included), f as for mgrt_slab_plan_vcycle.  Coarse levels run the default of 3 cycles as in the reference. */
+mgrt_status mgrt_slab_plan_fmg(mgrt_slab_plan *plan, void *u_out, const void *f, double omega, int a1, int a2, int v,
+                               int iters);
 
 #ifdef __cplusplus
 }

@@ -70,7 +70,7 @@ _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "u
             "plan_create", "plan_destroy", "plan_levels", "plan_level_dims", "plan_set_cells",
             "plan_vcycle", "plan_fmg", "correct_smooth_sweep_supported", "sumsq_noalloc_f32",
             "rccl_unique_id", "rccl_selftest", "slab_plan_create", "slab_plan_destroy", "slab_plan_distributed_levels",
-            "slab_plan_uses_graph", "slab_plan_rows", "slab_plan_vcycle"]
+            "slab_plan_uses_graph", "slab_plan_rows", "slab_plan_vcycle", "slab_plan_fmg"]
 SYMBOLS = ["mgrt_" + n for n in _RUNTIME] + ["mgrt_%s_%s" % (k, s) for k in _KERNELS for s in ("f32", "f64")]
 
 _lib = None
@@ -107,6 +107,7 @@ def load():
         "slab_plan_destroy": [p],
         "slab_plan_rows": [p, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)],
         "slab_plan_vcycle": [p, p, p, d, i, i, i, i, C.POINTER(d)],
+        "slab_plan_fmg": [p, p, p, d, i, i, i, i],
     }
     for name, args in sig.items():
         f = getattr(lib, "mgrt_" + name)
@@ -527,3 +528,13 @@ class SlabPlan:
         check(load().mgrt_slab_plan_vcycle(self._h, _p(u), _p(f), omega, a1, a2, v, ncycles, hist))
         torch.cuda.current_stream().wait_stream(self.stream)
         return list(hist) if history else None
+
+    def fmg(self, u_out, f, omega=1.0, a1=2, a2=2, v=1, iters=3):
+        """Full multigrid from the right-hand side alone into this rank's rows of u_out (halo included)."""
+        import torch
+        assert u_out.is_contiguous() and f.is_contiguous() and u_out.dtype == self.dtype and f.dtype == self.dtype
+        lo, hi, _, _ = self.rows()
+        assert tuple(u_out.shape) == (self.shape[0], hi - lo, self.shape[2]) == tuple(f.shape)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        check(load().mgrt_slab_plan_fmg(self._h, _p(u_out), _p(f), omega, a1, a2, v, iters))
+        torch.cuda.current_stream().wait_stream(self.stream)

@@ -117,6 +117,7 @@ struct mgrt_slab_plan {
         int own0, own1;       // owned local rows
         size_t n;             // elements stored
         void *work = nullptr, *r = nullptr, *rhs = nullptr, *e = nullptr;
+        void *fmg_f = nullptr, *fmg_u = nullptr; // FMG: restricted right-hand side and solution, allocated on first use
         void *sendbuf[2] = {nullptr, nullptr}, *recvbuf[2] = {nullptr, nullptr}; // [0] lower neighbour, [1] upper
         size_t halo_bytes = 0;
     };
@@ -127,6 +128,7 @@ struct mgrt_slab_plan {
     mgrt_grid cgrid;
     mgrt_plan *coarse = nullptr;
     void *c_rhs = nullptr, *c_e = nullptr, *gather_in = nullptr, *gather_out = nullptr;
+    void *c_fmg_f = nullptr, *c_fmg_u = nullptr; // FMG on the first level held whole, allocated on first use
     int maxrows = 0;
     double *d_norms = nullptr;
     int norms_cap = 0;
@@ -253,14 +255,14 @@ mgrt_status exchange_on(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, void *field
     return MGRT_OK;
 }
 
-// Every rank has written its own rows of the first undistributed level's right-hand side into c_rhs;
-// afterwards every rank holds all rows.
-mgrt_status gather_coarse(mgrt_slab_plan *p)
+// Every rank has written its own rows of an array of the first undistributed level (`whole`: c_rhs in a
+// cycle); afterwards every rank holds all rows.
+mgrt_status gather_coarse(mgrt_slab_plan *p, void *whole)
 {
     const size_t w = elem(p), row = (size_t)p->cnx * w, plane = row * p->cny;
     const size_t part = (size_t)p->cnz * p->maxrows * row; // bytes per rank in the gather buffers
     const int a = p->crow0[p->rank], b = p->crow1[p->rank];
-    MGRT_HIP(hipMemcpy2DAsync(p->gather_in, p->maxrows * row, (const char *)p->c_rhs + a * row, plane, (b - a) * row, p->cnz,
+    MGRT_HIP(hipMemcpy2DAsync(p->gather_in, p->maxrows * row, (const char *)whole + a * row, plane, (b - a) * row, p->cnz,
                               hipMemcpyDeviceToDevice, p->stream));
     if (p->tr.kind == MGRT_TRANSPORT_RCCL) {
         Rccl *nc = p->nc;
@@ -277,7 +279,7 @@ mgrt_status gather_coarse(mgrt_slab_plan *p)
         if (r == p->rank)
             continue;
         const int ra = p->crow0[r], rb = p->crow1[r];
-        MGRT_HIP(hipMemcpy2DAsync((char *)p->c_rhs + ra * row, plane, (const char *)p->gather_out + r * part, p->maxrows * row,
+        MGRT_HIP(hipMemcpy2DAsync((char *)whole + ra * row, plane, (const char *)p->gather_out + r * part, p->maxrows * row,
                                   (rb - ra) * row, p->cnz, hipMemcpyDeviceToDevice, p->stream));
     }
     return MGRT_OK;
@@ -291,6 +293,7 @@ template <> struct K<float> {
     static constexpr auto residual = mgrt_residual_f32;
     static constexpr auto restrict_ = mgrt_restrict_f32;
     static constexpr auto correct = mgrt_correct_f32;
+    static constexpr auto prolong = mgrt_prolong_f32;
     static constexpr auto sumsq = mgrt_sumsq_f32;
 };
 template <> struct K<double> {
@@ -300,6 +303,7 @@ template <> struct K<double> {
     static constexpr auto residual = mgrt_residual_f64;
     static constexpr auto restrict_ = mgrt_restrict_f64;
     static constexpr auto correct = mgrt_correct_f64;
+    static constexpr auto prolong = mgrt_prolong_f64;
     static constexpr auto sumsq = mgrt_sumsq_f64;
 };
 
@@ -391,7 +395,7 @@ mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1,
             const int a = p->crow0[p->rank], b = p->crow1[p->rank];
             if (mgrt_status st = K<R>::restrict_(&L.g, &p->cgrid, (R *)p->c_rhs, (const R *)L.r, a, b, s))
                 return st;
-            if (mgrt_status st = gather_coarse(p))
+            if (mgrt_status st = gather_coarse(p, p->c_rhs))
                 return st;
             if (mgrt_status st = mgrt_zero(p->c_e, (size_t)p->cnx * p->cny * p->cnz * sizeof(R), s))
                 return st;
@@ -444,6 +448,59 @@ template <class R> mgrt_status cycle_body(mgrt_slab_plan *p, R *u, const R *f, R
         return st;
     if (res != u)
         MGRT_HIP(hipMemcpyAsync(u, res, p->lv[0].n * sizeof(R), hipMemcpyDeviceToDevice, p->stream));
+    return MGRT_OK;
+}
+
+// fmg() of multigridsolver3D.cpp:82-109 on distributed level l: this rank's rows of the solution into u_out,
+// f with valid halo rows.  Launched directly (it runs once per solve).
+template <class R>
+mgrt_status fmg_level(mgrt_slab_plan *p, int l, R *u_out, const R *f, R omega, int a1, int a2, int v, int iters)
+{
+    mgrt_slab_plan::Level &L = p->lv[l];
+    mgrt_stream s = (mgrt_stream)p->stream;
+    if (l + 1 == p->ndist) {
+        const size_t cn = (size_t)p->cnx * p->cny * p->cnz * sizeof(R);
+        if (!p->c_fmg_f) {
+            MGRT_HIP(hipMalloc(&p->c_fmg_f, cn));
+            MGRT_HIP(hipMalloc(&p->c_fmg_u, cn));
+        }
+        // the right-hand side itself is restricted, unscaled (:98-99); every rank its rows, then all of them
+        if (mgrt_status st = K<R>::restrict_(&L.g, &p->cgrid, (R *)p->c_fmg_f, f, p->crow0[p->rank], p->crow1[p->rank], s))
+            return st;
+        if (mgrt_status st = gather_coarse(p, p->c_fmg_f))
+            return st;
+        // the recursive call omits iters, so coarse levels run the default of 3 (:101)
+        if (mgrt_status st = mgrt_plan_fmg(p->coarse, p->c_fmg_u, p->c_fmg_f, omega, a1, a2, v, 3))
+            return st;
+        if (mgrt_status st = K<R>::prolong(&L.g, &p->cgrid, u_out, (const R *)p->c_fmg_u, 0, L.nyl, s))
+            return st;
+    } else {
+        mgrt_slab_plan::Level &C = p->lv[l + 1];
+        if (!C.fmg_f) {
+            MGRT_HIP(hipMalloc(&C.fmg_f, C.n * sizeof(R)));
+            MGRT_HIP(hipMalloc(&C.fmg_u, C.n * sizeof(R)));
+            MGRT_HIP(hipMemsetAsync(C.fmg_f, 0, C.n * sizeof(R), p->stream)); // halo rows nobody fills start defined
+        }
+        if (mgrt_status st = K<R>::restrict_(&L.g, &C.g, (R *)C.fmg_f, f, C.own0, C.own1, s))
+            return st;
+        if (mgrt_status st = exchange(p, C, C.fmg_f))
+            return st;
+        if (mgrt_status st = fmg_level<R>(p, l + 1, (R *)C.fmg_u, (const R *)C.fmg_f, omega, a1, a2, v, 3))
+            return st;
+        if (mgrt_status st = exchange(p, C, C.fmg_u))
+            return st;
+        if (mgrt_status st = K<R>::prolong(&L.g, &C.g, u_out, (const R *)C.fmg_u, 0, L.nyl, s))
+            return st;
+    }
+    // every local row was interpolated, halo rows included
+    bool halo_valid = true;
+    for (int i = 0; i < iters; ++i) { // mg(), multigridsolver3D.h:49-59
+        R *res = nullptr;
+        if (mgrt_status st = iterate<R>(p, l, u_out, f, omega, a1, a2, v, halo_valid, &res))
+            return st;
+        if (res != u_out)
+            MGRT_HIP(hipMemcpyAsync(u_out, res, L.n * sizeof(R), hipMemcpyDeviceToDevice, p->stream));
+    }
     return MGRT_OK;
 }
 
@@ -775,10 +832,10 @@ mgrt_status mgrt_slab_plan_destroy(mgrt_slab_plan *p)
     drop_graph(p);
     (void)mgrt_plan_destroy(p->coarse);
     for (auto &L : p->lv) {
-        for (void *a : {L.work, L.r, L.rhs, L.e, L.sendbuf[0], L.sendbuf[1], L.recvbuf[0], L.recvbuf[1]})
+        for (void *a : {L.work, L.r, L.rhs, L.e, L.fmg_f, L.fmg_u, L.sendbuf[0], L.sendbuf[1], L.recvbuf[0], L.recvbuf[1]})
             (void)hipFree(a);
     }
-    for (void *a : {p->c_rhs, p->c_e, p->gather_in, p->gather_out, (void *)p->d_norms})
+    for (void *a : {p->c_rhs, p->c_e, p->c_fmg_f, p->c_fmg_u, p->gather_in, p->gather_out, (void *)p->d_norms})
         (void)hipFree(a);
     if (p->comm && p->nc)
         (void)p->nc->CommDestroy(p->comm);
@@ -824,6 +881,19 @@ mgrt_status mgrt_slab_plan_vcycle(mgrt_slab_plan *p, void *u, const void *f, dou
     if (p->desc.elem_size == 4)
         return vcycle<float>(p, (float *)u, (const float *)f, (float)omega, a1, a2, v, ncycles, res_hist);
     return vcycle<double>(p, (double *)u, (const double *)f, omega, a1, a2, v, ncycles, res_hist);
+}
+
+mgrt_status mgrt_slab_plan_fmg(mgrt_slab_plan *p, void *u_out, const void *f, double omega, int a1, int a2, int v, int iters)
+{
+    if (mgrt_status st = require_init()) return st;
+    MGRT_REQUIRE(p && u_out && f, "mgrt_slab_plan_fmg: null argument");
+    MGRT_REQUIRE(u_out != f, "mgrt_slab_plan_fmg: u_out and f are the same array");
+    MGRT_REQUIRE(a1 >= 0 && a2 >= 0 && v >= 0 && iters >= 0, "mgrt_slab_plan_fmg: negative count");
+    if (!p->ndist) // too small to cut (or one rank): the whole grid with the one-GPU plan
+        return mgrt_plan_fmg(p->coarse, u_out, f, omega, a1, a2, v, iters);
+    if (p->desc.elem_size == 4)
+        return fmg_level<float>(p, 0, (float *)u_out, (const float *)f, (float)omega, a1, a2, v, iters);
+    return fmg_level<double>(p, 0, (double *)u_out, (const double *)f, omega, a1, a2, v, iters);
 }
 
 } // extern "C"

@@ -5,7 +5,8 @@ torch.distributed.run; exits non-zero when this rank's rows differ from the whol
 
 BACKEND cpu: gloo, CPU tensors, oracle-backed kernels, the Python driver (multigrid_amd/dist.py).
 BACKEND gpu: the same driver with the HIP kernels, every rank on cuda:0, gloo with host staging.
-BACKEND native: mgrt_slab_plan of libmgrt.so (the C++ driver) on cuda:0 with callbacks over gloo."""
+BACKEND native: mgrt_slab_plan of libmgrt.so (the C++ driver) on cuda:0 with callbacks over gloo.
+BACKEND native-fmg: the same plan's full multigrid (NCYCLES = its iters) against the oracle's fmg."""
 import os
 import sys
 
@@ -43,10 +44,15 @@ def main():
         r = np.zeros_like(x)
         o.residual(cell, r, x, f)
         return o.l2norm_exact(r)
-    hist_ref.append(norm(ref))
-    for _ in range(ncycles):
-        o.iterate(ref, f, dt(omega), a1, a2, v, zfull)
+    fmg = backend == "native-fmg"
+    if fmg:
+        backend = "native"
+        ref = o.fmg(f, dt(omega), a1, a2, v, ncycles, zfull)
+    else:
         hist_ref.append(norm(ref))
+        for _ in range(ncycles):
+            o.iterate(ref, f, dt(omega), a1, a2, v, zfull)
+            hist_ref.append(norm(ref))
 
     tdt = torch.float32 if dt == np.float32 else torch.float64
     if backend == "cpu":
@@ -68,7 +74,12 @@ def main():
         lo, hi, a, b = cyc.local_rows()
     assert ndist >= 1, "this case does not split: pick a larger grid or a smaller crossover"
     ul, fl = cyc.scatter(to(u0)), cyc.scatter(to(f))
-    hist = cyc.vcycle(ul, fl, omega, a1, a2, v, ncycles, history=True)
+    if fmg:
+        ul.fill_(float("nan"))  # the result does not depend on what the array held
+        cyc.fmg(ul, fl, omega, a1, a2, v, ncycles)
+        hist = []
+    else:
+        hist = cyc.vcycle(ul, fl, omega, a1, a2, v, ncycles, history=True)
     if device is not None:
         torch.cuda.synchronize()
     mine = cyc.owned(ul).cpu().numpy()

@@ -89,6 +89,23 @@ def test_native_slab_plan_matches_whole_grid(case):
     launch(world, "native", shape, dtype, omega, a1, a2, v, ncycles, zfull, crossover)
 
 
+FMG_CASES = [
+    # ncycles is fmg's `iters` on the finest level (coarser levels run 3, as in the reference)
+    (2, (33, 65, 65), "f32", 1.0, 2, 2, 1, 1, True, 9 ** 3),
+    (2, (65, 129, 33), "f64", 0.9, 3, 1, 2, 2, True, 17 ** 3),
+    (3, (33, 129, 33), "f32", 1.0, 2, 2, 1, 3, False, 9 ** 3),
+    (2, (9, 641, 513), "f32", 1.0, 2, 2, 1, 1, True, 5 * 321 * 257),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", FMG_CASES, ids=lambda c: "w%d-%s-%s" % (c[0], "x".join(map(str, c[1])), c[2]))
+def test_native_slab_plan_fmg_matches_whole_grid(case):
+    """mgrt_slab_plan_fmg: every rank's rows bit for bit those of the oracle's whole-grid fmg."""
+    world, shape, dtype, omega, a1, a2, v, iters, zfull, crossover = case
+    launch(world, "native-fmg", shape, dtype, omega, a1, a2, v, iters, zfull, crossover)
+
+
 @pytest.mark.gpu
 def test_native_slab_plan_513_cubed_two_ranks():
     """The benchmark's grid cut in two: one V(2,2) cycle at 513^3, every rank's rows bit for bit those of
