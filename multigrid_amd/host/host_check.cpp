@@ -3,6 +3,8 @@
 //
 //   host_check OUT DIM NX NY NZ MODE OMEGA A1 A2 V ITERS FULLZ DOMAIN
 //     MODE    mg | fmg | sor | steps   (steps: one cycle spelled out with the step methods)
+//             slab2mg | slab3mg | slab2fmg   3D box: the solve by 2 or 3 distributed solvers, one thread each,
+//                                            every one holding its rows only (MultigridSolver3D::distribute)
 //     DOMAIN  box | map                (map: a domain with Neumann and outer cells, through
 //                                       MappedBorderHandler; the same rule as in the test)
 //   OUT receives: int32 nx, ny, nz, elem_size; then f, u, r, err as dense arrays; then 5 doubles:
@@ -11,11 +13,14 @@
 #include "functionhandler.h"
 #include "rectangularborderhandler.h"
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #ifndef M_PI
@@ -66,6 +71,162 @@ template <class Array> void put(FILE *fp, const Array &a, size_t n)
         throw std::runtime_error("short write");
 }
 
+// ---- ranks as threads of this process: a callback transport through host memory ------------------
+struct Hub {
+    explicit Hub(int n) : world(n), box(n * n), full(n * n, 0), arrived(0), generation(0), sum(0) {}
+    const int world;
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<std::vector<char> > box; // [from * world + to]: what `from` has posted for `to`
+    std::vector<int> full;
+    int arrived, generation;             // a barrier that can be used again
+    std::vector<char> gathered;
+    double sum;
+    // the last to arrive runs `last` (under the lock), then all leave
+    template <class F> void barrier(F last)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const int gen = generation;
+        if (++arrived == world) {
+            last();
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else
+            while (gen == generation)
+                cv.wait(lk);
+    }
+};
+struct Rank {
+    Hub *hub;
+    int rank;
+};
+void nothing() {}
+
+int cb_sendrecv(void *ctx, int n, const int *peers, void *const *send, void *const *recv, const size_t *bytes)
+{
+    Rank *me = (Rank *)ctx;
+    Hub &h = *me->hub;
+    for (int k = 0; k < n; ++k) {
+        const int slot = me->rank * h.world + peers[k];
+        std::vector<char> tmp(bytes[k]);
+        if (mgrt_download(tmp.data(), send[k], bytes[k], 0) != MGRT_OK)
+            return 1;
+        std::unique_lock<std::mutex> lk(h.m);
+        while (h.full[slot])
+            h.cv.wait(lk);
+        h.box[slot].swap(tmp);
+        h.full[slot] = 1;
+        h.cv.notify_all();
+    }
+    for (int k = 0; k < n; ++k) {
+        const int slot = peers[k] * h.world + me->rank;
+        std::vector<char> tmp;
+        {
+            std::unique_lock<std::mutex> lk(h.m);
+            while (!h.full[slot])
+                h.cv.wait(lk);
+            tmp.swap(h.box[slot]);
+            h.full[slot] = 0;
+            h.cv.notify_all();
+        }
+        if (tmp.size() != bytes[k] || mgrt_upload(recv[k], tmp.data(), bytes[k], 0) != MGRT_OK)
+            return 1;
+    }
+    return 0;
+}
+
+int cb_allgather(void *ctx, const void *send, void *recv, size_t bytes)
+{
+    Rank *me = (Rank *)ctx;
+    Hub &h = *me->hub;
+    std::vector<char> mine(bytes);
+    if (mgrt_download(mine.data(), send, bytes, 0) != MGRT_OK)
+        return 1;
+    {
+        std::unique_lock<std::mutex> lk(h.m);
+        h.gathered.resize(bytes * h.world);
+        memcpy(&h.gathered[bytes * me->rank], mine.data(), bytes);
+    }
+    h.barrier(nothing); // all parts are in
+    const bool ok = mgrt_upload(recv, h.gathered.data(), bytes * h.world, 0) == MGRT_OK;
+    h.barrier(nothing); // all have read before the next call writes
+    return ok ? 0 : 1;
+}
+
+int cb_allreduce_sum(void *ctx, double *value)
+{
+    Rank *me = (Rank *)ctx;
+    Hub &h = *me->hub;
+    double v = 0;
+    if (mgrt_download(&v, value, sizeof v, 0) != MGRT_OK)
+        return 1;
+    // summed in rank order so that every run gives the same bits
+    static std::vector<double> parts;
+    {
+        std::unique_lock<std::mutex> lk(h.m);
+        parts.resize(h.world);
+        parts[me->rank] = v;
+    }
+    h.barrier([&h]() {
+        h.sum = 0;
+        for (int r = 0; r < h.world; ++r)
+            h.sum += parts[r];
+    });
+    const double total = h.sum;
+    h.barrier(nothing);
+    return mgrt_upload(value, &total, sizeof total, 0) == MGRT_OK ? 0 : 1;
+}
+
+// The solve of `mode` by `world` distributed solvers; returns the whole field gathered on the host.
+std::vector<real> solve_distributed(const Args &a, int world, const std::string &mode, const std::vector<real> &f_whole)
+{
+    Hub hub(world);
+    std::vector<real> u_whole((size_t)a.nx * a.ny * a.nz, (real)0);
+    std::vector<std::string> errors(world);
+    std::vector<std::thread> threads;
+    for (int r = 0; r < world; ++r)
+        threads.push_back(std::thread([&, r]() {
+            try {
+                Rank me = {&hub, r};
+                mgrt_transport t = mgrt_transport();
+                t.kind = MGRT_TRANSPORT_CALLBACK;
+                t.rank = r, t.nranks = world;
+                t.ctx = &me;
+                t.sendrecv = cb_sendrecv, t.allgather = cb_allgather, t.allreduce_sum = cb_allreduce_sum;
+                ParallelepipedalBorderHandler box;
+                MultigridSolver3D solver("mg_1.cl", box);
+                solver.setFullZRange(a.fullz != 0);
+                solver.distribute(t, a.ny, /*crossover*/ 9 * 9 * 9);
+                int lo, hi, own_lo, own_hi;
+                solver.slabRows(a.nx, a.nz, &lo, &hi, &own_lo, &own_hi);
+                const int rows = hi - lo;
+                std::vector<real> fl((size_t)a.nx * rows * a.nz), ul(fl.size(), (real)0);
+                for (int z = 0; z < a.nz; ++z)
+                    memcpy(&fl[(size_t)z * rows * a.nx], &f_whole[((size_t)z * a.ny + lo) * a.nx], sizeof(real) * rows * a.nx);
+                Buffer3D f(a.nx, rows, a.nz, fl.data());
+                Buffer3D u(a.nx, rows, a.nz, ul.data());
+                if (mode == "mg")
+                    solver.mg(u, f, a.omega, a.a1, a.a2, a.v, a.iters);
+                else
+                    u = solver.fmg(f, a.omega, a.a1, a.a2, a.v, a.iters);
+                solver.wait();
+                TridimArray<real> got = u.read(solver.queue());
+                for (int z = 0; z < a.nz; ++z) // rows of different ranks do not overlap
+                    memcpy(&u_whole[((size_t)z * a.ny + own_lo) * a.nx], got.data() + ((size_t)z * rows + (own_lo - lo)) * a.nx,
+                           sizeof(real) * (own_hi - own_lo) * a.nx);
+            } catch (const std::exception &e) {
+                errors[r] = e.what();
+            }
+        }));
+    for (int r = 0; r < world; ++r)
+        threads[r].join();
+    for (int r = 0; r < world; ++r)
+        if (!errors[r].empty())
+            throw std::runtime_error("rank " + std::to_string(r) + ": " + errors[r]);
+    return u_whole;
+}
+
 int run3(const Args &a)
 {
     ParallelepipedalBorderHandler box;
@@ -81,7 +242,14 @@ int run3(const Args &a)
         solver.mg(u, f, a.omega, a.a1, a.a2, a.v, a.iters);
     else if (a.mode == "fmg")
         u = solver.fmg(f, a.omega, a.a1, a.a2, a.v, a.iters);
-    else if (a.mode == "sor")
+    else if (a.mode.compare(0, 4, "slab") == 0 && a.mode.size() > 5) {
+        if (a.domain != "box")
+            throw std::runtime_error("distributed solves take box domains");
+        TridimArray<real> fh_host = f.read(solver.queue());
+        const std::vector<real> f_whole(fh_host.data(), fh_host.data() + (size_t)a.nx * a.ny * a.nz);
+        std::vector<real> got = solve_distributed(a, a.mode[4] - '0', a.mode.substr(5), f_whole);
+        u = Buffer3D(a.nx, a.ny, a.nz, got.data());
+    } else if (a.mode == "sor")
         solver.smoother_iterate(u, f, a.omega, a.a1);
     else if (a.mode == "steps") {
         // one two-grid cycle from the public step methods

@@ -3,12 +3,78 @@
 
 namespace mgrt { namespace detail {
 
-SolverCore::SolverCore(int dim, const Binder &bind) : fullZRange(false), useGraph(true), m_dim(dim), m_bind(bind) {}
+SolverCore::SolverCore(int dim, const Binder &bind)
+    : fullZRange(false), useGraph(true), m_dim(dim), m_bind(bind), m_distributed(false), m_transport(), m_globalHeight(0),
+      m_crossover(0)
+{
+}
 
 SolverCore::~SolverCore()
 {
     for (std::map<Dims, PlanEntry>::iterator it = m_plans.begin(); it != m_plans.end(); ++it)
         (void)mgrt_plan_destroy(it->second.plan);
+    for (std::map<Dims, SlabEntry>::iterator it = m_slabs.begin(); it != m_slabs.end(); ++it)
+        (void)mgrt_slab_plan_destroy(it->second.plan);
+}
+
+void SolverCore::distribute(const mgrt_transport &t, int globalHeight, long long crossover)
+{
+    if (m_dim != 3)
+        throw Error("distribute: 3D grids only", MGRT_E_UNSUPPORTED);
+    for (std::map<Dims, SlabEntry>::iterator it = m_slabs.begin(); it != m_slabs.end(); ++it)
+        (void)mgrt_slab_plan_destroy(it->second.plan);
+    m_slabs.clear();
+    m_distributed = true;
+    m_transport = t;
+    m_globalHeight = globalHeight;
+    m_crossover = crossover;
+}
+
+mgrt_slab_plan *SolverCore::slabFor(const Dims &whole)
+{
+    std::map<Dims, SlabEntry>::iterator it = m_slabs.find(whole);
+    if (it != m_slabs.end()) {
+        if (it->second.zfull == fullZRange && it->second.graph == useGraph)
+            return it->second.plan;
+        (void)mgrt_slab_plan_destroy(it->second.plan);
+        m_slabs.erase(it);
+    }
+    const mgrt_grid top = describe(whole);
+    if (top.cells)
+        throw Error("distribute: box domains only (the border handler describes this grid by a cell map)", MGRT_E_UNSUPPORTED);
+    mgrt_slab_desc d;
+    d.nx = whole.w;
+    d.ny = whole.h;
+    d.nz = whole.d;
+    d.elem_size = (int)sizeof(real);
+    for (int i = 0; i < 6; ++i)
+        d.face[i] = top.face[i];
+    d.zfull = fullZRange ? 1 : 0;
+    d.use_graph = useGraph ? 1 : 0;
+    d.crossover = m_crossover;
+    SlabEntry e = {0, fullZRange, useGraph};
+    MGRT_CHECK(mgrt_slab_plan_create(&e.plan, &d, &m_transport, m_queue.get()));
+    m_slabs[whole] = e;
+    return e.plan;
+}
+
+void SolverCore::slabRows(int width, int depth, int *lo, int *hi, int *ownLo, int *ownHi)
+{
+    if (!m_distributed)
+        throw Error("slabRows: call distribute first", MGRT_E_INVALID);
+    const Dims whole = {width, m_globalHeight, depth};
+    MGRT_CHECK(mgrt_slab_plan_rows(slabFor(whole), lo, hi, ownLo, ownHi));
+}
+
+mgrt_slab_plan *SolverCore::slabForRows(const Dims &local)
+{
+    const Dims whole = {local.w, m_globalHeight, local.d};
+    mgrt_slab_plan *p = slabFor(whole);
+    int lo = 0, hi = 0;
+    MGRT_CHECK(mgrt_slab_plan_rows(p, &lo, &hi, 0, 0));
+    if (hi - lo != local.h)
+        throw Error("a distributed solver takes the rows slabRows names: this array has a different height", MGRT_E_INVALID);
+    return p;
 }
 
 mgrt_grid SolverCore::describe(const Dims &n)
@@ -131,6 +197,10 @@ mgrt_plan *SolverCore::planFor(const Dims &n)
 
 bool SolverCore::cycle(real *u, const real *f, const Dims &n, real omega, int a1, int a2, int v, int cycles)
 {
+    if (m_distributed) {
+        MGRT_CHECK(mgrt_slab_plan_vcycle(slabForRows(n), u, f, (double)omega, a1, a2, v, cycles, 0));
+        return true;
+    }
     mgrt_plan *p = planFor(n);
     if (!p)
         return false;
@@ -140,6 +210,10 @@ bool SolverCore::cycle(real *u, const real *f, const Dims &n, real omega, int a1
 
 bool SolverCore::fmg(real *out, const real *f, const Dims &n, real omega, int a1, int a2, int v, int iters)
 {
+    if (m_distributed) {
+        MGRT_CHECK(mgrt_slab_plan_fmg(slabForRows(n), out, f, (double)omega, a1, a2, v, iters));
+        return true;
+    }
     mgrt_plan *p = planFor(n);
     if (!p)
         return false;

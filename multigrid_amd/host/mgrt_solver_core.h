@@ -47,6 +47,14 @@ public:
     bool cycle(real *u, const real *f, const Dims &n, real omega, int a1, int a2, int v, int cycles);
     bool fmg(real *out, const real *f, const Dims &n, real omega, int a1, int a2, int v, int iters);
 
+    // Not in the reference (one device, one queue): from here on this solver is one rank of `t` (one process
+    // or thread per GPU) and cycle() / fmg() take this rank's rows of a 3D box `globalHeight` rows high, cut
+    // along y (mgrt_slab_plan_* of libmgrt.so).  Levels of at most `crossover` points are solved whole on
+    // every rank.  Box domains only.  The step kernels above keep working on whole arrays.
+    void distribute(const mgrt_transport &t, int globalHeight, long long crossover);
+    // the rows [lo, hi) this rank stores of a width x globalHeight x depth grid and the rows it owns
+    void slabRows(int width, int depth, int *lo, int *hi, int *ownLo, int *ownHi);
+
     // 3D only: relax every z plane instead of the reference's first ceil(nz/2)
     // (multigridsolver3D.cpp:121).  Off by default: results then match the reference's.
     bool fullZRange;
@@ -68,11 +76,22 @@ private:
         bool zfull, graph;
     };
     mgrt_plan *planFor(const Dims &n);
+    struct SlabEntry {
+        mgrt_slab_plan *plan;
+        bool zfull, graph;
+    };
+    mgrt_slab_plan *slabFor(const Dims &whole);
+    mgrt_slab_plan *slabForRows(const Dims &local); // checks that `local` is this rank's share
 
     int m_dim;
     Binder m_bind;
     Stream m_queue;
     std::map<Dims, PlanEntry> m_plans;
+    bool m_distributed;
+    mgrt_transport m_transport;
+    int m_globalHeight;
+    long long m_crossover;
+    std::map<Dims, SlabEntry> m_slabs; // keyed by the extents of the whole grid
 };
 
 }} // namespace mgrt::detail

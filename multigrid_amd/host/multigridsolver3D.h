@@ -50,6 +50,17 @@ public:
     // Not in the reference: relax all z planes (see SolverCore::fullZRange) / graph replay.
     void setFullZRange(bool on) { m_core.fullZRange = on; }
     void setUseGraph(bool on) { m_core.useGraph = on; }
+    // Not in the reference: make this solver one rank of several (one process or thread per GPU).  iterate,
+    // mg and fmg then take this rank's rows, slabRows(...) of them, of a box `globalHeight` rows high that is
+    // cut along y; every rank calls them together.  Results are bitwise those of one GPU.
+    void distribute(const mgrt_transport &t, int globalHeight, long long crossover = 129LL * 129 * 129)
+    {
+        m_core.distribute(t, globalHeight, crossover);
+    }
+    void slabRows(int width, int depth, int *lo, int *hi, int *ownLo, int *ownHi)
+    {
+        m_core.slabRows(width, depth, lo, hi, ownLo, ownHi);
+    }
 
 private:
     Buffer3D iterateSteps(Buffer3D &in, const Buffer3D &func, real omega, int a1, int a2, int v);

@@ -95,6 +95,8 @@ def oracle_solve(mgo, dt, dim, n, mode, omega, a1, a2, v, iters, fullz):
     shape = (nz, ny, nx) if dim == 3 else (ny, nx)
     f, sol = mgo.discretize(0 if dim == 3 else 2, shape, dt)
     u = np.zeros(shape, dt)
+    if mode.startswith("slab"):
+        mode = mode[5:]  # the same solve, whoever computes it
     if mode in ("mg", "debug"):
         mgo.mg(u, f, dt(omega), a1, a2, v, iters, fullz)
     elif mode == "fmg":
@@ -131,6 +133,10 @@ CASES = [
     (3, (18, 17, 21), "mg", 1.0, 2, 2, 1, 2, 1, "box"),      # an even extent: the step-by-step path, runs only
     (3, (33, 33, 33), "steps", 0.8, 2, 2, 1, 1, 0, "box"),
     (3, (9, 9, 9), "sor", 1.2, 5, 0, 1, 1, 0, "box"),
+    # MultigridSolver3D::distribute: 2 or 3 solvers, each a thread holding its rows only
+    (3, (33, 65, 17), "slab2mg", 1.0, 2, 2, 1, 2, 1, "box"),
+    (3, (17, 129, 33), "slab3mg", 0.9, 3, 1, 2, 1, 0, "box"),
+    (3, (33, 65, 33), "slab2fmg", 1.0, 2, 2, 1, 2, 1, "box"),
     (2, (33, 33, 1), "mg", 1.0, 2, 2, 1, 4, 0, "box"),
     (2, (65, 33, 1), "fmg", 2.0 / 3.0, 3, 3, 2, 3, 0, "box"),
     (2, (33, 65, 1), "mg", 0.9, 2, 2, 2, 2, 0, "map"),
@@ -161,6 +167,8 @@ def test_host_classes_match_oracle(mgo, tmp_path, dt, case):
     tol = 1e-5 if dt == np.float32 else 1e-12
     scale = max(1.0, float(np.abs(ru).max()))
     assert np.abs(u.astype(np.float64) - ru).max() <= tol * scale
+    if mode.startswith("slab"):
+        assert np.array_equal(u.view(np.uint8), ru.view(np.uint8)), "the distributed solve differs from the whole-grid one"
     assert np.abs(r.astype(np.float64) - rr).max() <= tol * max(1.0, float(np.abs(rr).max())) * 8
     assert np.abs(err.astype(np.float64) - rerr).max() <= tol * scale
     if np.array_equal(r.view(np.uint8), rr.view(np.uint8)):
