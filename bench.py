@@ -250,7 +250,7 @@ def main():
     ap.add_argument("--no-weak", action="store_true",
                     help="N > 1: skip the separately timed legs beside the line's own (the grid that grows with the "
                          "ranks, the 1025^3 double-precision grid)")
-    ap.add_argument("--crossover", type=int, default=129 ** 3,
+    ap.add_argument("--crossover", type=int, default=129 * 129 * 257,
                     help="N > 1: levels with at most this many points are solved whole on every rank")
     ap.add_argument("--transport", choices=("rccl", "gloo"), default="rccl",
                     help="N > 1: how halos travel (gloo: blocking host callbacks; chosen by itself when RCCL does not come up)")

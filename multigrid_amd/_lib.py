@@ -461,7 +461,7 @@ class SlabPlan:
     None with (rank, nranks) for the stand-alone share of one rank."""
 
     def __init__(self, shape, dtype, transport=None, rank=0, nranks=1, rccl_id=None, faces=ALL_DIRICHLET, zfull=True,
-                 use_graph=True, crossover=129 ** 3, stream=None):
+                 use_graph=True, crossover=129 * 129 * 257, stream=None):
         import torch
         d = SlabDesc()
         d.nz, d.ny, d.nx = shape

@@ -339,20 +339,24 @@ int zcount_of(const mgrt_slab_plan *p, const mgrt_slab_plan::Level &L)
 // `a` iterations as sweeps of two (and one odd one), each preceded by the exchange its halo needs.
 // With `res` the last sweep also leaves f - A u there, good on the rows whose stencil stays inside the
 // owned rows (the rows next to them were smoothed from halo rows that are stale by then).
+// `zero`: the field is known to be zero everywhere and `cur` has not been cleared; the first sweep then
+// reads no input at all (a null input stands for zeros), as in the one-GPU plan.
 template <class R>
 mgrt_status smooth(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, R *&cur, R *&alt, const R *f, R omega, int a, bool &halo_valid,
-                   R *res = nullptr)
+                   R *res = nullptr, bool zero = false)
 {
     mgrt_stream s = (mgrt_stream)p->stream;
     for (int left = a; left > 0;) {
         const int n = left >= 2 ? 2 : 1;
-        if (!halo_valid)
+        const R *in = zero ? nullptr : cur;
+        if (!halo_valid && !zero)
             if (mgrt_status st = exchange(p, L, cur))
                 return st;
+        zero = false;
         if (res && left == n) {
-            if (mgrt_status st = K<R>::sweep_res(&L.g, alt, res, cur, f, omega, n, zcount_of(p, L), s))
+            if (mgrt_status st = K<R>::sweep_res(&L.g, alt, res, in, f, omega, n, zcount_of(p, L), s))
                 return st;
-        } else if (mgrt_status st = K<R>::sweep(&L.g, alt, cur, f, omega, n, zcount_of(p, L), s))
+        } else if (mgrt_status st = K<R>::sweep(&L.g, alt, in, f, omega, n, zcount_of(p, L), s))
             return st;
         R *t = cur;
         cur = alt, alt = t;
@@ -365,15 +369,21 @@ mgrt_status smooth(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, R *&cur, R *&alt
 // iterate() on distributed level l; u and f are this rank's rows.  *result is the array that holds
 // the outcome (u or the level's work array).
 template <class R>
-mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1, int a2, int v, bool &halo_valid, R **result)
+mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1, int a2, int v, bool &halo_valid, R **result,
+                    bool u_is_zero = false)
 {
     mgrt_slab_plan::Level &L = p->lv[l];
     mgrt_stream s = (mgrt_stream)p->stream;
     R *cur = u, *alt = (R *)L.work;
+    if (u_is_zero && a1 == 0) { // nothing reads the zeros through a sweep first: write them
+        if (mgrt_status st = mgrt_zero(u, L.n * sizeof(R), s))
+            return st;
+        u_is_zero = false;
+    }
     // As on one GPU, the last pre-smoothing sweep of a bandwidth-bound level in single precision carries
     // the residual pass along (slabs too thin for strips of four rows: measured slower than the two kernels).
     const bool res_in_sweep = a1 > 0 && v > 0 && sizeof(R) == 4 && !latency_bound_level(L.g) && L.own1 - L.own0 > 2;
-    if (mgrt_status st = smooth<R>(p, L, cur, alt, f, omega, a1, halo_valid, res_in_sweep ? (R *)L.r : nullptr))
+    if (mgrt_status st = smooth<R>(p, L, cur, alt, f, omega, a1, halo_valid, res_in_sweep ? (R *)L.r : nullptr, u_is_zero))
         return st;
     const bool last = l + 1 == p->ndist;
     for (int it = 0; it < v; ++it) {
@@ -432,11 +442,10 @@ mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1,
                 return st;
             if (mgrt_status st = exchange(p, C, C.rhs))
                 return st;
-            if (mgrt_status st = mgrt_zero(C.e, C.n * sizeof(R), s))
-                return st;
+            // the coarse unknown starts from zero (zero_mem, multigridsolver3D.cpp:59) without being cleared
             bool ok = true;
             R *res = nullptr;
-            if (mgrt_status st = iterate<R>(p, l + 1, (R *)C.e, (const R *)C.rhs, omega, a1, a2, v, ok, &res))
+            if (mgrt_status st = iterate<R>(p, l + 1, (R *)C.e, (const R *)C.rhs, omega, a1, a2, v, ok, &res, true))
                 return st;
             if (!ok)
                 if (mgrt_status st = exchange(p, C, res))

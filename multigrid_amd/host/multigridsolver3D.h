@@ -53,7 +53,7 @@ public:
     // Not in the reference: make this solver one rank of several (one process or thread per GPU).  iterate,
     // mg and fmg then take this rank's rows, slabRows(...) of them, of a box `globalHeight` rows high that is
     // cut along y; every rank calls them together.  Results are bitwise those of one GPU.
-    void distribute(const mgrt_transport &t, int globalHeight, long long crossover = 129LL * 129 * 129)
+    void distribute(const mgrt_transport &t, int globalHeight, long long crossover = 129LL * 129 * 257)
     {
         m_core.distribute(t, globalHeight, crossover);
     }

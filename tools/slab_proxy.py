@@ -8,7 +8,7 @@ lower bound of the N-GPU cycle time, and T_1 / (N * T_N) an upper bound of the p
 keeps about 512 rows), where the share of a rank stays a full one-GPU problem and only the exchanges and
 the gathered coarse levels come on top.
 
-usage: tools/slab_proxy.py [--n 513] [--f64] [--crossover 2146689] [--cycles 20] [--weak]"""
+usage: tools/slab_proxy.py [--n 513] [--f64] [--crossover 4276737] [--cycles 20] [--weak]"""
 import argparse
 import json
 import os
@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=513)
     ap.add_argument("--f64", action="store_true")
-    ap.add_argument("--crossover", type=int, default=129 ** 3)
+    ap.add_argument("--crossover", type=int, default=129 * 129 * 257)
     ap.add_argument("--cycles", type=int, default=20)
     ap.add_argument("--ranks", default="1,2,4,8")
     ap.add_argument("--weak", action="store_true", help="the grid grows with the ranks: n x (512 N + 1) x n")
