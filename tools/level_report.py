@@ -29,16 +29,23 @@ def main():
             for r in csv.DictReader(fh):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    # the cycles end with the sweep that follows the last correction; what bench.py launches after
-    # that (its timing loop over the dominant kernel) is not part of a cycle
-    # (on bandwidth-bound levels that sweep applies the correction itself: last template argument)
+    # The last cycle ends where its way up from the last bottom launch is back on level 0: count the
+    # restrictions before that launch down and the interpolations after it up.  What bench.py launches
+    # after that (its timing loop over the dominant kernel) is not part of a cycle.
     def corrects(name):
         m = re.search(r"k_smooth3d_fused<([^>]*)>", name)
         return bool(m) and m.group(1).split(",")[7].strip() == "true"  # <R, ITERS, SR, NW, PD, OMEGA1, RES, COR, STAGES, MAP>
-    last = max((i for i, r in enumerate(rows) if "k_interp3d_v" in r[2] or corrects(r[2])), default=None)
-    if last is not None:
-        end = last if corrects(rows[last][2]) else next(
-            (i for i in range(last + 1, len(rows)) if "k_smooth3d_fused" in rows[i][2]), len(rows) - 1)
+    bottoms = [i for i, r in enumerate(rows) if "k_bottom_cycle" in r[2]]
+    if bottoms:
+        # V-cycles: every cycle restricts the same number of times before its one bottom launch
+        depth = sum("k_restrict" in r[2] for r in rows[:bottoms[-1]]) // len(bottoms)
+        end = bottoms[-1]
+        while depth > 0 and end + 1 < len(rows):
+            end += 1
+            if "k_interp3d_v" in rows[end][2] or corrects(rows[end][2]):
+                depth -= 1
+        if not corrects(rows[end][2]):  # the post-smoothing sweep after a correction of its own
+            end = next((j for j in range(end + 1, len(rows)) if "k_smooth3d_fused" in rows[j][2]), len(rows) - 1)
         rows = rows[:end + 1]
     agg = defaultdict(list)
     level = 0

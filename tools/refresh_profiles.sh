@@ -20,6 +20,13 @@ cd "$root" || exit 1
 cp "$out"/trace/bench_kernel_stats.csv "$out/bench_kernel_stats.csv" || exit 1
 python3 tools/trace_summary.py "$out/trace" > "$out/bench_kernel_trace_summary.txt" || exit 1
 python3 tools/level_report.py "$out/trace" 513 4 > "$out/per_level.txt" || exit 1
+# the same per-level report for the double-precision grids
+for n in 513 1025; do
+  cd /tmp
+  timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$out/trace${n}d" -o bench -- python3 "$root/bench.py" --config 3d${n}f64 --steps 6 --warmup 2 --no-cpu > "$out/bench_3d${n}f64_under_rocprof.json" 2>> "$out/rocprof.err" || exit 1
+  cd "$root" || exit 1
+  python3 tools/level_report.py "$out/trace${n}d" $n 8 > "$out/per_level_${n}f64.txt" || exit 1
+done
 timeout -k 10 200 python3 tools/kbench.py > "$out/kbench513.txt" 2>&1 || exit 1
 bash tools/pmc.sh "$out/pmc" fetch,write || exit 1
 python3 tools/pmc_summary.py "$out/pmc" > "$out/pmc_fetch_write_kbench513.txt" || exit 1
@@ -46,5 +53,5 @@ done
 timeout -k 10 300 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu > "$out/rehearsal_gpus2.json" 2> "$out/rehearsal_gpus2.err" || exit 1
 timeout -k 10 400 python3 bench.py --gpus 8 --steps 3 --warmup 1 --no-cpu > "$out/rehearsal_gpus8.json" 2> "$out/rehearsal_gpus8.err" || exit 1
 timeout -k 10 60 tools/ubench/valu.bin > "$out/valu_rates.txt" 2>&1 || exit 1
-rm -rf "$out/trace"/*.db "$out"/pmc*/*/*.db
+rm -rf "$out"/trace*/*.db "$out"/trace*/*/*.db "$out"/pmc*/*/*.db
 echo refreshed
