@@ -391,9 +391,21 @@ mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1,
         // whose stencil stays inside the owned rows are formed while the halo of the unknown travels,
         // the two rows at either end afterwards.
         const int rlo = L.y0 > 0 ? L.own0 - 1 : L.own0, rhi = L.y1 < L.gny ? L.own1 + 1 : L.own1;
+        // where the restricted residual goes: this rank's rows [c0, c1) of the next level
+        const mgrt_grid *cg = last ? &p->cgrid : &p->lv[l + 1].g;
+        R *crhs = last ? (R *)p->c_rhs : (R *)p->lv[l + 1].rhs;
+        const int c0 = last ? p->crow0[p->rank] : p->lv[l + 1].own0, c1 = last ? p->crow1[p->rank] : p->lv[l + 1].own1;
+        bool restricted = false;
         if (res_in_sweep && it == 0) {
-            // the sweep left the rows in between; the two at either end need the neighbours' rows
-            if (mgrt_status st = exchange(p, L, cur))
+            // The sweep left the rows in between; the two at either end need the neighbours' rows.  While
+            // those travel, the coarse rows that only read what the sweep left are restricted.
+            if (mgrt_status st = exchange_begin(p, L, cur))
+                return st;
+            const bool split = c1 - c0 > 2;
+            if (split)
+                if (mgrt_status st = K<R>::restrict_(&L.g, cg, crhs, (const R *)L.r, c0 + 1, c1 - 1, s))
+                    return st;
+            if (mgrt_status st = exchange_end(p))
                 return st;
             halo_valid = true;
             const int ilo = L.own0 + 1, ihi = L.own1 - 1;
@@ -401,6 +413,13 @@ mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1,
                 return st;
             if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, ihi, rhi, s))
                 return st;
+            if (split) {
+                if (mgrt_status st = K<R>::restrict_(&L.g, cg, crhs, (const R *)L.r, c0, c0 + 1, s))
+                    return st;
+                if (mgrt_status st = K<R>::restrict_(&L.g, cg, crhs, (const R *)L.r, c1 - 1, c1, s))
+                    return st;
+                restricted = true;
+            }
         } else if (!halo_valid && L.own1 - L.own0 > 2) {
             if (mgrt_status st = exchange_begin(p, L, cur))
                 return st;
@@ -426,9 +445,9 @@ mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1,
         const R *e_local;
         const mgrt_grid *egrid;
         if (last) {
-            const int a = p->crow0[p->rank], b = p->crow1[p->rank];
-            if (mgrt_status st = K<R>::restrict_(&L.g, &p->cgrid, (R *)p->c_rhs, (const R *)L.r, a, b, s))
-                return st;
+            if (!restricted)
+                if (mgrt_status st = K<R>::restrict_(&L.g, cg, crhs, (const R *)L.r, c0, c1, s))
+                    return st;
             if (mgrt_status st = gather_coarse(p, p->c_rhs))
                 return st;
             if (mgrt_status st = mgrt_zero(p->c_e, (size_t)p->cnx * p->cny * p->cnz * sizeof(R), s))
@@ -438,8 +457,9 @@ mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1,
             e_local = (const R *)p->c_e, egrid = &p->cgrid;
         } else {
             mgrt_slab_plan::Level &C = p->lv[l + 1];
-            if (mgrt_status st = K<R>::restrict_(&L.g, &C.g, (R *)C.rhs, (const R *)L.r, C.own0, C.own1, s))
-                return st;
+            if (!restricted)
+                if (mgrt_status st = K<R>::restrict_(&L.g, cg, crhs, (const R *)L.r, c0, c1, s))
+                    return st;
             if (mgrt_status st = exchange(p, C, C.rhs))
                 return st;
             // the coarse unknown starts from zero (zero_mem, multigridsolver3D.cpp:59) without being cleared
