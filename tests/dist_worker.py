@@ -1,7 +1,9 @@
 """One rank of a slab-decomposed V-cycle test.  Launched by tests/test_dist.py through
 torch.distributed.run; exits non-zero when this rank's rows differ from the whole-grid oracle.
 
-  dist_worker.py BACKEND NZ NY NX DTYPE OMEGA A1 A2 V NCYCLES ZFULL CROSSOVER
+  dist_worker.py BACKEND NZ NY NX DTYPE OMEGA A1 A2 V NCYCLES ZFULL CROSSOVER [FACES]
+
+FACES: six cell classes x-lo,x-hi,y-lo,y-hi,z-lo,z-hi (2 Dirichlet, 3 Neumann), default all Dirichlet.
 
 BACKEND cpu: gloo, CPU tensors, oracle-backed kernels, the Python driver (multigrid_amd/dist.py).
 BACKEND gpu: the same driver with the HIP kernels, every rank on cuda:0, gloo with host staging.
@@ -26,6 +28,7 @@ def main():
     omega, a1, a2, v, ncycles, zfull, crossover = (float(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8]),
                                                    int(sys.argv[9]), int(sys.argv[10]), bool(int(sys.argv[11])),
                                                    int(sys.argv[12]))
+    faces = tuple(int(c) for c in sys.argv[13].split(",")) if len(sys.argv) > 13 else (2,) * 6
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     import _oracle
@@ -38,7 +41,18 @@ def main():
     u0 = rng.standard_normal(shape).astype(dt)
     ref = u0.copy()
     hist_ref = []
-    cell = o.box_cells(shape)
+    cell = o.box_cells(shape, faces)
+    if faces != (2,) * 6:
+        def rule(x, y, z, mx, my, mz):  # y faces win over x faces over z faces, on every level
+            if y == 0: return faces[2]
+            if y == my - 1: return faces[3]
+            if x == 0: return faces[0]
+            if x == mx - 1: return faces[1]
+            if z == 0: return faces[4]
+            if z == mz - 1: return faces[5]
+            return 0
+        o.set_celltype(rule)
+        assert np.array_equal(o.level_cells(shape), cell), "the rule and box_cells disagree"
 
     def norm(x):
         r = np.zeros_like(x)
@@ -65,11 +79,12 @@ def main():
         device = torch.device("cuda", 0)
     to = (lambda a: torch.from_numpy(a.copy())) if device is None else (lambda a: torch.from_numpy(a.copy()).to(device))
     if backend == "native":
-        cyc = kernels.SlabPlan(shape, tdt, transport=kernels.GlooTransport(), zfull=zfull, crossover=crossover)
+        cyc = kernels.SlabPlan(shape, tdt, transport=kernels.GlooTransport(), zfull=zfull, crossover=crossover, faces=faces)
         ndist = cyc.distributed_levels
         lo, hi, a, b = cyc.rows()
     else:
-        cyc = slab.SlabCycle(shape, tdt, kernels=kernels, device=device, zfull=zfull, crossover=crossover)
+        cyc = slab.SlabCycle(shape, tdt, kernels=kernels, device=device, zfull=zfull, crossover=crossover,
+                             faces=faces if faces != (2,) * 6 else None)
         ndist = cyc.ndist
         lo, hi, a, b = cyc.local_rows()
     assert ndist >= 1, "this case does not split: pick a larger grid or a smaller crossover"

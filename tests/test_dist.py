@@ -19,11 +19,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(world, backend, shape, dtype, omega, a1, a2, v, ncycles, zfull, crossover, timeout=300):
+def launch(world, backend, shape, dtype, omega, a1, a2, v, ncycles, zfull, crossover, timeout=300, faces=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(HERE, "dist_worker.py"), backend] + [str(s) for s in shape] + \
-          [dtype, repr(float(omega)), str(a1), str(a2), str(v), str(ncycles), str(int(zfull)), str(crossover)]
+          [dtype, repr(float(omega)), str(a1), str(a2), str(v), str(ncycles), str(int(zfull)), str(crossover)] + \
+          ([",".join(map(str, faces))] if faces else [])
     env = dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     if p.returncode != 0:
@@ -104,6 +105,17 @@ def test_native_slab_plan_fmg_matches_whole_grid(case):
     """mgrt_slab_plan_fmg: every rank's rows bit for bit those of the oracle's whole-grid fmg."""
     world, shape, dtype, omega, a1, a2, v, iters, zfull, crossover = case
     launch(world, "native-fmg", shape, dtype, omega, a1, a2, v, iters, zfull, crossover)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world, shape, dtype, faces", [
+    (2, (33, 65, 65), "f32", (2, 2, 3, 3, 2, 3)),    # the faces the slabs are cut along are Neumann (frozen rows)
+    (3, (17, 129, 33), "f64", (3, 2, 2, 3, 3, 2)),
+    (2, (9, 641, 513), "f32", (2, 3, 3, 2, 2, 2)),   # wide slabs: the sweeps with residual and with correction
+], ids=["w2-yN", "w3-mixed", "w2-wide"])
+def test_native_slab_plan_with_neumann_faces(world, shape, dtype, faces):
+    launch(world, "native", shape, dtype, 1.0, 2, 2, 1, 2, True, 9 ** 3 if shape[2] < 100 else 5 * 321 * 257, faces=faces)
+    launch(world, "native-fmg", shape, dtype, 0.9, 2, 1, 1, 1, True, 9 ** 3 if shape[2] < 100 else 5 * 321 * 257, faces=faces)
 
 
 @pytest.mark.gpu
