@@ -17,3 +17,29 @@ def test_rccl_operations_direct_and_from_a_graph():
     torch.cuda.synchronize()
     # and the library still works afterwards
     assert len(_lib.rccl_unique_id()) == 128
+
+
+@pytest.mark.parametrize("shape, dt", [((33, 129, 65), "f32"), ((17, 129, 33), "f64"), ((9, 1283, 513), "f32")],
+                         ids=["small", "f64", "wide"])
+def test_slab_cycle_replayed_from_a_graph_equals_direct_launches(shape, dt):
+    """The share of a middle rank with the stand-alone transport (what it would receive is what it packed,
+    copied on the device): the captured cycle -- kernels, halo kernels, copies, the side stream forked and
+    joined by events -- must leave the same bits as the same cycle launched directly."""
+    _lib.init(0)
+    tdt = torch.float32 if dt == "f32" else torch.float64
+    dev = torch.device("cuda", 0)
+    outs = []
+    for graph in (True, False):
+        plan = _lib.SlabPlan(shape, tdt, transport=None, rank=1, nranks=4, zfull=True, crossover=9 ** 3, use_graph=graph)
+        assert plan.distributed_levels >= 1
+        lo, hi, _, _ = plan.rows()
+        g = torch.Generator(device="cpu").manual_seed(5)
+        f = torch.randn((shape[0], hi - lo, shape[2]), generator=g, dtype=tdt).to(dev)
+        u = torch.randn((shape[0], hi - lo, shape[2]), generator=g, dtype=tdt).to(dev)
+        hist = plan.vcycle(u, f, 1.0, 2, 2, 1, 3, history=True)
+        torch.cuda.synchronize()
+        assert bool(plan.uses_graph) == graph
+        outs.append((u.cpu(), hist))
+        plan.close()
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
