@@ -1,4 +1,5 @@
-"""The RCCL binding of libmgrt.so as far as one GPU can exercise it: a communicator of one rank."""
+"""What one GPU can tell about the several-GPU path: the RCCL binding on a communicator of one rank, and the
+captured slab cycle against direct launches."""
 import pytest
 
 torch = pytest.importorskip("torch")
