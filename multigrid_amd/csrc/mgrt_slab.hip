@@ -205,6 +205,7 @@ mgrt_status halo_rows(const mgrt_slab_plan *p, const mgrt_slab_plan::Level &L, v
     }
     c.slab_words = L.g.slab * (long long)wpe;
     c.seg_words = (unsigned)(kHalo * (size_t)L.g.pitch * wpe);
+    MGRT_REQUIRE(L.nz <= 65535, "mgrt_slab_plan: %d planes are more than one launch of the halo kernel covers", L.nz);
     unsigned bx = (c.seg_words + 255u) / 256u;
     if (bx > 64u)
         bx = 64u;
