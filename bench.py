@@ -21,7 +21,8 @@ reported as "fixed_grid_1025_f64" (--no-weak skips both).  On a box with fewer t
 the ranks share the devices and the halos go through host callbacks over gloo (a rehearsal of the path,
 marked as such in the output, not a measurement).  Each rank does its work in a child process and watches
 it: when an attempt fails or stops making progress on any rank, all ranks go on to the next one (RCCL with
-the cycle in a graph, RCCL with direct launches, host callbacks), and the line says which attempts failed.
+the cycle in a graph, RCCL with direct launches, the same without the extra timed regions, host callbacks),
+and the line says which attempts failed.
 """
 import argparse
 import json
@@ -171,7 +172,8 @@ ATTEMPTS = (
     # fails or stops making progress (a collective that never returns cannot be left from inside)
     ("RCCL, cycle in one graph", []),
     ("RCCL, direct launches", ["--no-graph"]),
-    ("host callbacks over gloo", ["--no-graph", "--transport", "gloo"]),
+    ("RCCL, direct launches, the line's own workload only", ["--no-graph", "--no-weak"]),
+    ("host callbacks over gloo, the line's own workload only", ["--no-graph", "--no-weak", "--transport", "gloo"]),
 )
 PHASE_LIMIT_S = {"start": 420.0}  # the first import of torch on a fresh box pages the image in
 PHASE_LIMIT_DEFAULT_S = float(os.environ.get("MGRT_BENCH_PHASE_LIMIT_S", "150"))

@@ -21,6 +21,6 @@ def test_ranks_without_a_gpu_walk_the_attempts_and_give_up():
     assert not [line for line in p.stdout.splitlines() if line.startswith("{")]
     # the launcher ends the other rank as soon as one has given up, so the last line of one of them may be missing
     for rank in (0, 1):
-        assert 2 <= p.stderr.count("bench.py rank %d:" % rank) <= 3, p.stderr[-3000:]
-    assert "trying: RCCL, direct launches" in p.stderr and "trying: host callbacks over gloo" in p.stderr
+        assert 3 <= p.stderr.count("bench.py rank %d:" % rank) <= 4, p.stderr[-3000:]
+    assert "trying: RCCL, direct launches" in p.stderr and "trying: host callbacks over gloo, the line's own workload only" in p.stderr
     assert "giving up" in p.stderr and "no GPU visible" in p.stderr
