@@ -26,7 +26,7 @@ $(LIB): $(LIB_OBJS)
 
 # diagnostic build with in-kernel time stamps in the fused sweep (tools/stamps.py); not the product
 stamps:
-	$(HIPCC) $(HIPFLAGS) -DMGRT_STAMPS -shared -o multigrid_amd/libmgrt_stamps.so $(LIB_SRCS)
+	$(HIPCC) $(HIPFLAGS) -I$(CSRC) -shared -o multigrid_amd/libmgrt_stamps.so $(filter-out $(CSRC)/mgrt_smooth_fused.hip,$(LIB_SRCS)) tools/diag/mgrt_stamps.hip -ldl
 
 oracle:
 	$(MAKE) -C oracle

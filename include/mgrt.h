@@ -105,6 +105,8 @@ mgrt_status mgrt_box_cells_host(int dim, int nx, int ny, int nz, const int face[
 /* Whether mgrt_correct_smooth_sweep_f32/_f64 (below) has a kernel for this fine grid, element size
  * (4 or 8) and iteration count: 1 or 0.  For callers that plan their launches ahead. */
 int mgrt_correct_smooth_sweep_supported(const mgrt_grid *fine, int elem_size, int iters);
+/* The same question for mgrt_smooth_sweep_residual_restrict_f32/_f64. */
+int mgrt_smooth_sweep_residual_restrict_supported(const mgrt_grid *fine, int elem_size, int iters);
 
 #define MGRT_DECLARE_KERNELS(R, S)                                                                 \
     /* One colour pass of the weighted Gauss-Seidel smoother, in place.  Replaces                 \
@@ -133,12 +135,17 @@ int mgrt_correct_smooth_sweep_supported(const mgrt_grid *fine, int elem_size, in
                                               const R *f, R omega, int iters, int zcount,          \
                                               mgrt_stream s);                                      \
     /* The same sweep, which leaves rc = Restrict(residual of `out`) on the coarse grid behind     \
-       and never writes the fine residual: smoother_iterate, compute_residuals and restrict        \
-       (multigridsolver2D.cpp:51,62,71) in one pass over the fields.  Whole 2D analytic-box        \
-       grids with odd extents only (MGRT_E_UNSUPPORTED otherwise).  in == NULL: zeros. */          \
+       without a pass over the fine residual: smoother_iterate, compute_residuals and restrict     \
+       (multigridsolver2D.cpp:51,62,71, multigridsolver3D.cpp:50,61,64) in one pass over the       \
+       fields.  Whole analytic-box grids with odd extents; in 3D only where                        \
+       mgrt_smooth_sweep_residual_restrict_supported says so (MGRT_E_UNSUPPORTED otherwise).       \
+       r: 2D: not used, may be NULL.  3D: a work array of the fine grid's size; the sweep forms    \
+       every coarse row but those on the seams between its rows of tiles, leaves the fine          \
+       residual rows around those seams in r (the rest of r is not written) and a restriction of   \
+       the seam rows follows on the same stream.  in == NULL: zeros. */                            \
     mgrt_status mgrt_smooth_sweep_residual_restrict##S(const mgrt_grid *fine,                      \
                                                        const mgrt_grid *coarse, R *out, R *rc,     \
-                                                       const R *in, const R *f, R omega,           \
+                                                       R *r, const R *in, const R *f, R omega,     \
                                                        int iters, int zcount, mgrt_stream s);      \
     /* out = S^iters(u + 4*P(e)): the results of mgrt_correct followed by mgrt_smooth_sweep, the   \
        corrected field never written.  Replaces correct_residual followed by the post-smoothing    \
@@ -227,6 +234,9 @@ typedef struct mgrt_plan_desc {
     int neumann;      /* mgrt_grid.neumann for every level: 0 = the reference's frozen Neumann cells,
                          1 = first-order Neumann condition (extension; implies the unfused schedule
                          when a face is Neumann) */
+    int separate_restrict; /* 1: 3D levels write the fine residual and restrict it with a launch of its
+                         own even where the pre-smoothing sweep could carry the restriction (same
+                         values; for timing comparisons) */
 } mgrt_plan_desc;
 
 mgrt_status mgrt_plan_create(mgrt_plan **plan, const mgrt_plan_desc *desc, mgrt_stream s);

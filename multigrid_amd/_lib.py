@@ -35,7 +35,7 @@ class PlanDesc(C.Structure):
     _fields_ = [
         ("dim", C.c_int), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
         ("elem_size", C.c_int), ("face", C.c_int * 6), ("zfull", C.c_int), ("use_graph", C.c_int),
-        ("no_fuse", C.c_int), ("no_bottom", C.c_int), ("neumann", C.c_int),
+        ("no_fuse", C.c_int), ("no_bottom", C.c_int), ("neumann", C.c_int), ("separate_restrict", C.c_int),
     ]
 
 
@@ -68,7 +68,8 @@ _KERNELS = ["smooth_pass", "smooth", "smooth_sweep", "smooth_sweep_residual", "s
 _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "upload", "download",
             "stream_create", "stream_destroy", "sync", "zero", "box_cells_host",
             "plan_create", "plan_destroy", "plan_levels", "plan_level_dims", "plan_set_cells",
-            "plan_vcycle", "plan_fmg", "correct_smooth_sweep_supported", "sumsq_noalloc_f32",
+            "plan_vcycle", "plan_fmg", "correct_smooth_sweep_supported", "smooth_sweep_residual_restrict_supported",
+            "sumsq_noalloc_f32",
             "rccl_unique_id", "rccl_selftest", "slab_plan_create", "slab_plan_destroy", "slab_plan_distributed_levels",
             "slab_plan_uses_graph", "slab_plan_rows", "slab_plan_vcycle", "slab_plan_fmg"]
 SYMBOLS = ["mgrt_" + n for n in _RUNTIME] + ["mgrt_%s_%s" % (k, s) for k in _KERNELS for s in ("f32", "f64")]
@@ -120,6 +121,8 @@ def load():
         getattr(lib, "mgrt_" + name).argtypes = [p]
     lib.mgrt_correct_smooth_sweep_supported.restype = i
     lib.mgrt_correct_smooth_sweep_supported.argtypes = [G, i, i]
+    lib.mgrt_smooth_sweep_residual_restrict_supported.restype = i
+    lib.mgrt_smooth_sweep_residual_restrict_supported.argtypes = [G, i, i]
     for S, r in (("f32", C.c_float), ("f64", C.c_double)):
         ksig = {
             "smooth_pass": [G, p, p, r, i, i, i, i, p],
@@ -127,7 +130,7 @@ def load():
             "smooth_sweep": [G, p, p, p, r, i, i, p],
             "smooth_sweep_residual": [G, p, p, p, p, r, i, i, p],
             "correct_smooth_sweep": [G, G, p, p, p, p, r, i, i, p],
-            "smooth_sweep_residual_restrict": [G, G, p, p, p, p, r, i, i, p],
+            "smooth_sweep_residual_restrict": [G, G, p, p, p, p, p, r, i, i, p],
             "residual": [G, p, p, p, i, p, i, i, p],
             "restrict": [G, G, p, p, i, i, p],
             "correct": [G, G, p, p, p, i, i, p],
@@ -232,9 +235,16 @@ def correct_smooth_sweep(fine, coarse, out, u, e, f, omega, iters, zcount=None, 
                                            fine.nz if zcount is None else zcount, _stream(stream)))
 
 
-def smooth_sweep_residual_restrict(fine, coarse, out, rc, inp, f, omega, iters, zcount=None, stream=None):
-    check(_fn("smooth_sweep_residual_restrict", f)(C.byref(fine), C.byref(coarse), _p(out), _p(rc), _p(inp), _p(f), omega,
-                                                     iters, fine.nz if zcount is None else zcount, _stream(stream)))
+def restrict_sweep_supported(fine, dtype, iters):
+    """Whether smooth_sweep_residual_restrict has a kernel for this fine grid, torch dtype and iteration count."""
+    import torch
+    return bool(load().mgrt_smooth_sweep_residual_restrict_supported(C.byref(fine), 4 if dtype == torch.float32 else 8, iters))
+
+
+def smooth_sweep_residual_restrict(fine, coarse, out, rc, inp, f, omega, iters, zcount=None, stream=None, r=None):
+    """r: 3D only, a work array of the fine grid's size (the fine residual next to tile seams passes through it)."""
+    check(_fn("smooth_sweep_residual_restrict", f)(C.byref(fine), C.byref(coarse), _p(out), _p(rc), _p(r), _p(inp), _p(f),
+                                                     omega, iters, fine.nz if zcount is None else zcount, _stream(stream)))
 
 
 def smooth_sweep_residual(g, out, r, inp, f, omega, iters, zcount=None, stream=None):
@@ -316,7 +326,7 @@ class Plan:
     """mgrt_plan: pre-allocated hierarchy; iterate/mg/fmg of MultigridSolver{2,3}D on device arrays."""
 
     def __init__(self, shape, dtype, faces=ALL_DIRICHLET, zfull=False, use_graph=False, no_fuse=False, no_bottom=False, neumann=0,
-                 stream=None):
+                 stream=None, separate_restrict=False):
         import torch
         d = PlanDesc()
         if len(shape) == 3:
@@ -330,6 +340,7 @@ class Plan:
         d.no_fuse = int(no_fuse)
         d.no_bottom = int(no_bottom)
         d.neumann = int(neumann)
+        d.separate_restrict = int(separate_restrict)
         self.shape, self.dtype = tuple(shape), dtype
         self._h = C.c_void_p()
         check(load().mgrt_plan_create(C.byref(self._h), C.byref(d), _stream(stream)))

@@ -105,6 +105,22 @@ inline bool correct_sweep_3d_supported(const mgrt_grid *g, size_t elem, int iter
            g->nz % 2 == 1 && g->nz >= 5 && !latency_bound_level(*g) && plane_offsets_fit(g, elem) && !neumann_extension(g);
 }
 
+// Whether mgrt_smooth_sweep_residual_restrict has a 3D kernel for this level (the restriction carried in
+// the residual-carrying sweep): whole bandwidth-bound analytic boxes with odd extents, 4-byte elements,
+// two iterations.
+inline bool restrict_sweep_3d_supported(const mgrt_grid *g, size_t elem, int iters)
+{
+    return g->dim == 3 && elem == 4 && iters == 2 && !g->cells && g->y0 == 0 && g->ny == g->gny && g->nx % 2 == 1 &&
+           g->gny % 2 == 1 && g->nz % 2 == 1 && g->nz >= 5 && !latency_bound_level(*g) && plane_offsets_fit(g, elem) &&
+           !neumann_extension(g);
+}
+
+// Full-weighting restriction (mgrt_restrict) of `nrows` coarse rows j0, j0 + jstep, ... only.
+mgrt_status restrict_rows(const mgrt_grid *fine, const mgrt_grid *coarse, float *rc, const float *rf, int j0, int jstep,
+                          int nrows, hipStream_t hs);
+mgrt_status restrict_rows(const mgrt_grid *fine, const mgrt_grid *coarse, double *rc, const double *rf, int j0, int jstep,
+                          int nrows, hipStream_t hs);
+
 // out = S^iters(in) on a 2D analytic-box grid, iters 1 or 2 (mgrt_smooth2d.hip); in may be null.
 // res (optional) receives the residual of out or, when cg is given without e, its restriction to
 // the coarse grid cg; e with its coarse grid cg (optional) makes the input in + 4*P(e).

@@ -30,6 +30,27 @@ namespace {
 
 constexpr int kWave = 64;
 
+template <class R>
+mgrt_status restrict_rows_impl(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, const R *rf, int j0, int jstep, int nrows,
+                               hipStream_t hs);
+
+} // namespace
+
+namespace mgrt {
+mgrt_status restrict_rows(const mgrt_grid *fine, const mgrt_grid *coarse, float *rc, const float *rf, int j0, int jstep,
+                          int nrows, hipStream_t hs)
+{
+    return restrict_rows_impl<float>(fine, coarse, rc, rf, j0, jstep, nrows, hs);
+}
+mgrt_status restrict_rows(const mgrt_grid *fine, const mgrt_grid *coarse, double *rc, const double *rf, int j0, int jstep,
+                          int nrows, hipStream_t hs)
+{
+    return restrict_rows_impl<double>(fine, coarse, rc, rf, j0, jstep, nrows, hs);
+}
+} // namespace mgrt
+
+namespace {
+
 // ---- cell classes ---------------------------------------------------------------------------
 // Replaces getCellType/isBorder on a NaN-encoded Cell (mg_1.cl:14-26).  With a byte map the class
 // is one load; for a box it is index arithmetic and costs no memory traffic.
@@ -383,16 +404,16 @@ __global__ __launch_bounds__(256) void k_residual3d_v(mgrt_grid g, R *r, const R
 
 // ---- full-weighting restriction (mg_1.cl:146-190, mg_0.cl:139-157) ----------------------------
 // One thread per coarse point.  `fine`/`coarse` may be y-slabs: coarse global row jg maps to fine
-// global row 2*jg.
+// global row 2*jg.  Coarse rows cylo, cylo + jstep, ... (nrows of them).
 template <class R, int DIM, bool MAP, bool NEU = false>
 __global__ __launch_bounds__(256) void k_restrict(mgrt_grid fg, mgrt_grid cg, R *rc, const R *__restrict__ rf,
-                                                  int cylo, int cyhi, unsigned nbxy)
+                                                  int cylo, int nrows, unsigned nbxy, int jstep)
 {
     const unsigned bid = (unsigned)xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
     const unsigned idx = (bid % nbxy) * 256u + threadIdx.x;
-    if (idx >= (unsigned)cg.nx * (unsigned)(cyhi - cylo))
+    if (idx >= (unsigned)cg.nx * (unsigned)nrows)
         return;
-    const int j = cylo + (int)(idx / (unsigned)cg.nx), i = (int)(idx % (unsigned)cg.nx);
+    const int j = cylo + (int)(idx / (unsigned)cg.nx) * jstep, i = (int)(idx % (unsigned)cg.nx);
     const int k = DIM == 3 ? (int)(bid / nbxy) : 0;
     const int x = 2 * i, y = 2 * (j + cg.y0) - fg.y0, z = 2 * k;
     const long long p = fg.pitch, s = fg.slab;
@@ -830,15 +851,30 @@ mgrt_status restrict_fw(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, c
     hipStream_t hs = (hipStream_t)s;
     const bool map = fine->cells != nullptr;
     if (neumann_extension(fine)) {
-        if (fine->dim == 3) k_restrict<R, 3, false, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
-        else                k_restrict<R, 2, false, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
+        if (fine->dim == 3) k_restrict<R, 3, false, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi - cylo, nbxy, 1);
+        else                k_restrict<R, 2, false, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi - cylo, nbxy, 1);
     } else if (fine->dim == 3) {
-        if (map) k_restrict<R, 3, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
-        else     k_restrict<R, 3, false><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
+        if (map) k_restrict<R, 3, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi - cylo, nbxy, 1);
+        else     k_restrict<R, 3, false><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi - cylo, nbxy, 1);
     } else {
-        if (map) k_restrict<R, 2, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
-        else     k_restrict<R, 2, false><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi, nbxy);
+        if (map) k_restrict<R, 2, true><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi - cylo, nbxy, 1);
+        else     k_restrict<R, 2, false><<<grid, 256, 0, hs>>>(*fine, *coarse, rc, rf, cylo, cyhi - cylo, nbxy, 1);
     }
+    MGRT_HIP(hipGetLastError());
+    return MGRT_OK;
+}
+
+template <class R>
+mgrt_status restrict_rows_impl(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, const R *rf, int j0, int jstep, int nrows,
+                               hipStream_t hs)
+{
+    MGRT_REQUIRE(fine->dim == 3 && !fine->cells && !neumann_extension(fine) && fine->y0 == 0 && coarse->y0 == 0,
+                 "restrict_rows: whole 3D analytic boxes only");
+    if (nrows <= 0)
+        return MGRT_OK;
+    MGRT_REQUIRE(j0 >= 0 && jstep >= 1 && j0 + (long long)(nrows - 1) * jstep < coarse->ny, "restrict_rows: rows outside the grid");
+    const unsigned nbxy = blocks_for((long long)coarse->nx * nrows, 256);
+    k_restrict<R, 3, false><<<dim3(nbxy * (unsigned)coarse->nz), 256, 0, hs>>>(*fine, *coarse, rc, rf, j0, nrows, nbxy, jstep);
     MGRT_HIP(hipGetLastError());
     return MGRT_OK;
 }

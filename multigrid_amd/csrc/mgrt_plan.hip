@@ -146,7 +146,7 @@ mgrt_status smooth_steps(mgrt_plan *p, mgrt_plan::Level &L, R *&cur, R *&alt, co
         const R *in = cur_is_zero && i == 0 ? nullptr : cur;
         if (mgrt_status st = e && i == 0              ? K<R>::correct_sweep(&L.g, cg, alt, cur, e, f, omega, n, zc, s)
                              : res && i + 1 == nsweeps
-                                 ? (cg ? K<R>::sweep_res_restrict(&L.g, cg, alt, res, in, f, omega, n, zc, s)
+                                 ? (cg ? K<R>::sweep_res_restrict(&L.g, cg, alt, res, (R *)L.r, in, f, omega, n, zc, s)
                                        : K<R>::sweep_res(&L.g, alt, res, in, f, omega, n, zc, s))
                                                        : K<R>::sweep(&L.g, alt, in, f, omega, n, zc, s))
             return st;
@@ -196,8 +196,12 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
     const bool correct_in_sweep =
         n2 > 0 && a2 > 0 && v > 0 && recurses(L.g) &&
         (L.g.dim == 2 || correct_sweep_3d_supported(&L.g, sizeof(R), n2 < a2 ? 2 : 1));
-    // 2D: that sweep hands the coarse level its right-hand side directly (no fine residual array)
-    const bool restrict_in_sweep = res_in_sweep && L.g.dim == 2;
+    // That sweep hands the coarse level its right-hand side directly where a kernel for it exists: every 2D
+    // level, and in 3D the bandwidth-bound levels in single precision when it does two iterations (the
+    // fine residual is then written next to the seams between rows of tiles only).
+    const bool restrict_in_sweep =
+        res_in_sweep && (L.g.dim == 2 || (!p->desc.separate_restrict &&
+                                          mgrt_smooth_sweep_residual_restrict_supported(&L.g, (int)sizeof(R), n1 < a1 ? 2 : 1)));
     if (a1 > 0) {
         R *res = restrict_in_sweep ? (R *)p->lv[l + 1].rhs : res_in_sweep ? (R *)L.r : nullptr;
         if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a1, n1, res, u_is_zero,

@@ -25,6 +25,7 @@
 #include <dlfcn.h>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 using namespace mgrt;
@@ -55,9 +56,8 @@ constexpr int kNcclChar = 0, kNcclDouble = 8, kNcclSum = 0; // ncclDataType_t / 
 mgrt_status rccl(Rccl **out)
 {
     static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once; // solver threads of one process may arrive together
+    std::call_once(once, [] {
         // the copy a host framework has already loaded, when there is one
         for (const char *name : {"librccl.so.1", "librccl.so"}) {
             r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -78,7 +78,7 @@ mgrt_status rccl(Rccl **out)
             MGRT_SYM(GetErrorString, "ncclGetErrorString");
 #undef MGRT_SYM
         }
-    }
+    });
     if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd ||
         !r.AllGather || !r.AllReduce || !r.GetErrorString)
         return fail(MGRT_E_UNSUPPORTED, "RCCL (librccl.so.1) is not available: %s", r.lib ? "a symbol is missing" : dlerror());
@@ -134,6 +134,7 @@ struct mgrt_slab_plan {
     int norms_cap = 0;
     hipGraphExec_t exec = nullptr;
     bool graph_failed = false; // capture or instantiation was refused once: cycles are launched directly
+    bool broken = false;       // a transport call failed: halos may be stale, the plan refuses further work
     bool warmed = false;       // one cycle has run outside a capture (RCCL sets its connections up on first use)
     struct Key {
         void *u;
@@ -254,14 +255,26 @@ mgrt_status exchange_on(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, void *field
     if (mgrt_status st = halo_rows<false>(p, L, field, L.sendbuf, has, send_row, on))
         return st;
     if (p->tr.kind == MGRT_TRANSPORT_RCCL) {
+        // A group that was opened is always closed, whatever fails inside it: an error return between
+        // the two would leave every later RCCL call of this thread nested in it and never issued.
         Rccl *nc = p->nc;
         MGRT_NCCL(nc->GroupStart());
-        for (int k = 0; k < 2; ++k)
+        int err = 0;
+        const char *what = "ncclSend";
+        for (int k = 0; k < 2 && !err; ++k)
             if (has[k]) {
-                MGRT_NCCL(nc->Send(L.sendbuf[k], L.halo_bytes, kNcclChar, peer[k], p->comm, on));
-                MGRT_NCCL(nc->Recv(L.recvbuf[k], L.halo_bytes, kNcclChar, peer[k], p->comm, on));
+                err = nc->Send(L.sendbuf[k], L.halo_bytes, kNcclChar, peer[k], p->comm, on);
+                if (!err)
+                    what = "ncclRecv", err = nc->Recv(L.recvbuf[k], L.halo_bytes, kNcclChar, peer[k], p->comm, on);
             }
-        MGRT_NCCL(nc->GroupEnd());
+        const int end = nc->GroupEnd();
+        if (!err && end)
+            what = "ncclGroupEnd", err = end;
+        if (err) {
+            p->broken = true;
+            return fail(MGRT_E_TRANSPORT, "mgrt_slab_plan: %s with rank %d or %d failed: %s", what, peer[0], peer[1],
+                        nc->GetErrorString(err));
+        }
     } else if (p->tr.kind == MGRT_TRANSPORT_CALLBACK) {
         int peers[2], n = 0;
         void *send[2], *recv[2];
@@ -570,6 +583,8 @@ void drop_graph(mgrt_slab_plan *p)
 // transport can be captured; launched directly otherwise, and for good once a capture was refused.
 template <class R> mgrt_status run_cycle(mgrt_slab_plan *p, R *u, const R *f, R omega, int a1, int a2, int v)
 {
+    if (p->broken)
+        return fail(MGRT_E_TRANSPORT, "mgrt_slab_plan: a transport call failed earlier; create a new plan");
     if (!p->desc.use_graph || !capturable(p) || p->graph_failed || !p->warmed) {
         p->warmed = true;
         return cycle_body<R>(p, u, f, omega, a1, a2, v);
@@ -593,10 +608,20 @@ template <class R> mgrt_status run_cycle(mgrt_slab_plan *p, R *u, const R *f, R 
         if (graph)
             (void)hipGraphDestroy(graph);
         if (st != MGRT_OK || ei != hipSuccess) {
-            // nothing of the captured cycle has run: run it directly, now and from here on
+            // Nothing of the captured cycle has run.  A failed transport call ends the plan (its peers are
+            // out of step); anything else: run the cycle directly, now and from here on, once the side
+            // stream has left the abandoned capture as well.
             (void)hipGetLastError();
             p->exec = nullptr;
             p->graph_failed = true;
+            if (p->broken || st == MGRT_E_TRANSPORT) {
+                p->broken = true;
+                return st != MGRT_OK ? st : fail(MGRT_E_TRANSPORT, "mgrt_slab_plan: a transport call failed inside a capture");
+            }
+            if (p->side)
+                (void)hipStreamSynchronize(p->side);
+            (void)hipStreamSynchronize(p->stream);
+            (void)hipGetLastError();
             return cycle_body<R>(p, u, f, omega, a1, a2, v);
         }
         p->key = key;
@@ -696,9 +721,12 @@ mgrt_status mgrt_rccl_selftest(mgrt_stream s)
     hipGraphExec_t exec = nullptr;
     auto queue = [&]() -> mgrt_status {
         MGRT_NCCL(nc->GroupStart());
-        MGRT_NCCL(nc->Send(a, kBytes, kNcclChar, 0, comm, hs));
-        MGRT_NCCL(nc->Recv(b, kBytes, kNcclChar, 0, comm, hs));
-        MGRT_NCCL(nc->GroupEnd());
+        int err = nc->Send(a, kBytes, kNcclChar, 0, comm, hs);
+        if (!err)
+            err = nc->Recv(b, kBytes, kNcclChar, 0, comm, hs);
+        const int end = nc->GroupEnd(); // always closed, see exchange_on
+        if (err || end)
+            return fail(MGRT_E_TRANSPORT, "mgrt_rccl_selftest: send/receive group: %s", nc->GetErrorString(err ? err : end));
         MGRT_NCCL(nc->AllGather(b, c, kBytes, kNcclChar, comm, hs));
         MGRT_NCCL(nc->AllReduce(d, d + 1, 1, kNcclDouble, kNcclSum, comm, hs));
         return MGRT_OK;
@@ -932,6 +960,8 @@ mgrt_status mgrt_slab_plan_vcycle(mgrt_slab_plan *p, void *u, const void *f, dou
     MGRT_REQUIRE(p && u && f, "mgrt_slab_plan_vcycle: null argument");
     MGRT_REQUIRE(u != f, "mgrt_slab_plan_vcycle: u and f are the same array");
     MGRT_REQUIRE(a1 >= 0 && a2 >= 0 && v >= 0 && ncycles >= 0, "mgrt_slab_plan_vcycle: negative count");
+    if (p->broken)
+        return fail(MGRT_E_TRANSPORT, "mgrt_slab_plan_vcycle: a transport call failed earlier; create a new plan");
     if (p->desc.elem_size == 4)
         return vcycle<float>(p, (float *)u, (const float *)f, (float)omega, a1, a2, v, ncycles, res_hist);
     return vcycle<double>(p, (double *)u, (const double *)f, omega, a1, a2, v, ncycles, res_hist);
@@ -943,6 +973,8 @@ mgrt_status mgrt_slab_plan_fmg(mgrt_slab_plan *p, void *u_out, const void *f, do
     MGRT_REQUIRE(p && u_out && f, "mgrt_slab_plan_fmg: null argument");
     MGRT_REQUIRE(u_out != f, "mgrt_slab_plan_fmg: u_out and f are the same array");
     MGRT_REQUIRE(a1 >= 0 && a2 >= 0 && v >= 0 && iters >= 0, "mgrt_slab_plan_fmg: negative count");
+    if (p->broken)
+        return fail(MGRT_E_TRANSPORT, "mgrt_slab_plan_fmg: a transport call failed earlier; create a new plan");
     if (!p->ndist) // too small to cut (or one rank): the whole grid with the one-GPU plan
         return mgrt_plan_fmg(p->coarse, u_out, f, omega, a1, a2, v, iters);
     if (p->desc.elem_size == 4)

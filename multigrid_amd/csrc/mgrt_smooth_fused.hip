@@ -40,20 +40,14 @@ namespace {
 
 constexpr int kWave = 64;
 
-// Diagnostic build only (-DMGRT_STAMPS, tools/stamps.py): shader-clock time a wavefront spends in each
-// segment of a fast time step, summed over the march, for the wavefronts of the middle block.
-#ifdef MGRT_STAMPS
-__device__ unsigned long long mgrt_stamps[16][8];
-#define MGRT_STAMP_BEGIN() (tprev = __builtin_amdgcn_s_memtime())
-#define MGRT_STAMP(k)                                                                              \
-    do {                                                                                           \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                \
-        acc[k] += t_ - tprev;                                                                      \
-        tprev = t_;                                                                                \
-    } while (0)
-#else
+// Hooks of the diagnostic build (tools/diag/mgrt_stamps.hip defines them and includes this file: time a
+// wavefront spends in each segment of a fast time step).  Empty in the product.
+#ifndef MGRT_STAMP
+#define MGRT_STAMP_DECL()
 #define MGRT_STAMP_BEGIN()
 #define MGRT_STAMP(k)
+#define MGRT_STAMP_STEP()
+#define MGRT_STAMP_END(wave, lane)
 #endif
 
 //
@@ -70,7 +64,8 @@ __device__ unsigned long long mgrt_stamps[16][8];
 // first row must be even (globally), so that which rows and planes sit between coarse points is
 // known at compile time and the eight trilinear weights are per-lane constants.
 struct CoarseField {
-    const void *e;
+    const void *e; // COR: the coarse field to interpolate from
+    void *rc;      // RST: the coarse right-hand side to write
     long long pitch, slab;
     int nx, ny, nz, y0;
 };
@@ -89,12 +84,29 @@ template <class R> __device__ __forceinline__ R dot4(R a0, R a1, R a2, R a3, R b
 // latency of a step rather than bandwidth that is what counts.  The second group runs
 // LAG = 2*ITERS + 1 steps behind the first; both share the one barrier per step.
 //
+// RST (with RES) carries the full-weighting restriction (reduction_kernel, mg_1.cl:146-190) of that
+// residual along and writes it straight to the coarse right-hand side; the fine residual then never
+// reaches memory except next to the seams between tile rows (below).  A lane keeps the residuals of
+// its SR rows for the last three planes, split by colour as the rings are.  Coarse points sit at even
+// x, y, z: colour 0, on the upper row of a row pair (tiles start on odd rows), so an even lane holds a
+// coarse point's centre as its own colour-0 value, the rows above and below as its own colour-1 values
+// of this pair and the next one, and finds the six remaining in-plane values in its two neighbour
+// lanes (DPP).  The next pair of a strip's last pair comes from the strip below through LDS, a step
+// later, so coarse plane K is formed one step after the residual of fine plane 2K + 1.  The 27 terms
+// are summed in the reference's order; coarse points on a face of the grid take the fine value at
+// their place (mg_1.cl:154-160: for odd extents the forward 2x2x2 block of a coarse point touches a
+// border cell exactly when the point lies on a face).  A coarse point needs residuals one ring further
+// out than the tile stores values: in x the tiles are cut one column narrower on either side for it;
+// in y that would take more tiles than a 513^2 plane leaves CUs, so the coarse row on the seam between
+// two tile rows is left out here, the three fine residual rows around it are written to r, and a
+// restriction launch for those coarse rows alone follows.
+//
 // MAP: the domain is described by one byte per point (g.cells) instead of six face classes.  The
 // bytes of a plane are prefetched beside its values (SR more loads per lane and step), packed two bits
 // a row into one register per plane in flight, and looked up where the box variant uses per-lane
 // constants; nothing else changes, so any domain a BorderHandler can describe takes the fused sweep.
 template <class R, int ITERS, int SR, int NW, int PD, bool OMEGA1, bool RES, bool COR = false, int STAGES = 1,
-          bool MAP = false>
+          bool MAP = false, bool RST = false>
 __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid g, const R *__restrict__ in,
                                                               R *__restrict__ out, const R *__restrict__ f,
                                                               R *__restrict__ res, R omega, int zcount, int ntx,
@@ -104,8 +116,10 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     static_assert(!COR || (PD == 2 && !RES), "the corrected input is built for a prefetch depth of two planes");
     static_assert(STAGES == 1 || (STAGES == 2 && !RES && !COR), "stages hand on whole smoothed planes only");
     static_assert(!MAP || (STAGES == 1 && !RES && !COR && SR <= 16), "the byte-map variant is the plain sweep");
+    static_assert(!RST || (RES && !COR && STAGES == 1 && !MAP), "the restriction rides on the residual pass");
     constexpr int NP = 2 * ITERS, J = SR / 2;    // colour passes per stage
     constexpr int H = NP * STAGES + (RES ? 1 : 0); // halo rings consumed by all stages together
+    constexpr int HX = H + (RST ? 1 : 0);        // in x the restriction takes one more
     constexpr int LAG = NP + 1;                  // steps between a plane leaving one stage and entering the next
     constexpr int DR = NP + 2;             // ring depth of the residual pass
     constexpr int ND = RES ? NP + 4 : NP + 2, NSET = RES ? NP + 2 : NP;
@@ -114,8 +128,13 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     // i lives in ring slot i % ND and prefetch slot i % PD, nothing is ever shifted.
     static_assert(ND % PD == 0 || PD % ND == 0, "prefetch depth and ring depth must divide the unrolled loop");
     constexpr int UN = ND > PD ? ND : PD;
-    constexpr int OX = kWave - 2 * H, OY = NW * SR - 2 * H;
+    constexpr int OX = kWave - 2 * HX, OY = NW * SR - 2 * H;
+    // strips start on odd rows (coarse rows are the upper rows of their pairs), residual planes live in
+    // three slots addressed with a period of four planes
+    static_assert(!RST || (H % 2 == 1 && OY % 2 == 0 && UN % 4 == 0 && DR % 2 == 0), "tile shape does not fit the restriction");
     __shared__ R bnd[2][NSET][NW * STAGES][2][kWave];
+    // first row pair of every strip's residual plane, for the strip above: [step parity][strip][colour][lane]
+    __shared__ R rbn[2][RST ? NW : 1][2][kWave];
     // hand-over between the stages: [step parity][strip][u | f][colour][row pair][lane]; a wavefront of
     // the second stage reads exactly what the wavefront of the first stage with the same strip wrote
     __shared__ R hand[2][STAGES > 1 ? NW : 1][2][2][J][kWave];
@@ -130,7 +149,7 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     // time.  A speed matter only: any placement computes the same values.
     const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tx = tile % ntx, ty = tile / ntx;
-    const int x = tx * OX - H + lane;
+    const int x = tx * OX - HX + lane;
     const int ly0 = w * SR;               // first strip row inside the tile
     const int y0 = ty * OY - H + ly0;     // its array row
     const bool xin = x >= 0 && x < g.nx;
@@ -152,7 +171,7 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     for (int r = 0; r < SR; ++r) {
         const int y = y0 + r, yg = y + g.y0;
         const bool live = xin && y >= 0 && y < g.ny;
-        const bool keep = live && lane >= H && lane < kWave - H && ly0 + r >= H && ly0 + r < NW * SR - H;
+        const bool keep = live && lane >= HX && lane < kWave - HX && ly0 + r >= H && ly0 + r < NW * SR - H;
         const unsigned o = ((unsigned)x + (unsigned)g.pitch * (unsigned)y) * (unsigned)sizeof(R);
         off[r] = live ? o : kDrop;
         soff[r] = keep ? o : kDrop;
@@ -197,6 +216,31 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
         latfix[1][j] = latdir[1][j] && !interior[1][j];
     }
 
+    // Restriction: where this lane's coarse points go (one per row pair: its upper row), whether they lie
+    // on a lateral face of the grid, and where the two rows of a strip that can lie next to a seam
+    // between tile rows go in r (rows H and H + 1 of a tile below a seam, row NW*SR - H - 1 above one).
+    constexpr int RS0 = H % SR, RS1 = (H + 1) % SR;
+    static_assert(!RST || (NW * SR - H - 1) % SR == RS1 || (NW * SR - H - 1) % SR == RS0, "seam rows");
+    unsigned cof[RST ? J : 1], rof[2];
+    bool injl[RST ? J : 1];
+    if constexpr (RST) {
+        const int nty = (int)gridDim.x / ntx;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int r = 2 * j + 1, l = ly0 + r, y = y0 + r, yg = y + g.y0;
+            const bool own = xin && y >= 0 && y < g.ny && lane >= HX && lane < kWave - HX && (x & 1) == 0 &&
+                             ((l >= H + 2 && l < NW * SR - H) || (l == H && ty == 0));
+            cof[j] = own ? ((unsigned)(x >> 1) + (unsigned)cf.pitch * (unsigned)((yg >> 1) - cf.y0)) * (unsigned)sizeof(R) : kDrop;
+            injl[j] = x == 0 || x == g.nx - 1 || yg == 0 || yg == g.gny - 1;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r = k ? RS1 : RS0, l = ly0 + r;
+            const bool seam = (l == H || l == H + 1) ? ty > 0 : (l == NW * SR - H - 1 ? ty + 1 < nty : false);
+            rof[k] = seam ? soff[r] : kDrop;
+        }
+    }
+
     const long long slab = g.slab;
     const int zlast = g.nz - 1;
     const int zlim = zcount < g.nz ? zcount : g.nz;
@@ -207,13 +251,13 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     constexpr bool FIRST = STG == 0, LAST = STG == STAGES - 1; // FIRST loads from memory, LAST stores to it
     constexpr int lag = STG * LAG;
     constexpr int WB = STG * NW; // this stage's wavefronts in bnd
-    constexpr int kStores = LAST ? (RES ? 2 * SR : SR) : 0;            // per step
+    // per step; the coarse stores of every second step of RST are left out, which only makes the counted
+    // waits stricter than needed
+    constexpr int kStores = LAST ? (RST ? SR + 2 : RES ? 2 * SR : SR) : 0;
     constexpr int kLoads = MAP ? 3 * SR : 2 * SR;                     // per step
     constexpr int kYounger = kStores + (PD - 1) * (kLoads + kStores); // see wait_slot
     static_assert(kYounger < 64, "too many vector-memory operations in flight for a counted wait");
-#ifdef MGRT_STAMPS
-    unsigned long long acc[8] = {}, tprev = 0;
-#endif
+    MGRT_STAMP_DECL();
     R C[2][ND][J], F[2][ND][J];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -221,6 +265,18 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
         for (int d = 0; d < ND; ++d)
 #pragma unroll
             for (int j = 0; j < J; ++j) C[c][d][j] = F[c][d][j] = 0;
+    // RST: residuals of the last three planes, [slot][colour][row pair], pair J being the first pair of
+    // the strip below.  Odd planes alternate between slots 0 and 1, even planes use slot 2 (an even plane
+    // is the centre of one coarse plane only, an odd one serves two).
+    R Rr[RST ? 3 : 1][2][J + 1];
+#pragma unroll
+    for (int t = 0; t < (RST ? 3 : 1); ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j <= J; ++j) Rr[t][c][j] = 0;
+    R *const rcb = (R *)cf.rc;
+    const unsigned rcplane_bytes = RST ? (unsigned)(cf.pitch * (long long)cf.ny * (long long)sizeof(R)) : 0u;
 
     // ---- coarse-grid correction: offsets, weights, the two coarse planes in registers ----------
     constexpr int NCR = SR / 2 + 1; // coarse rows under SR fine rows that start on an even row
@@ -309,7 +365,7 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
 
     // planes entering this stage's ring: the last one finishes plane nz-1; all stages together take
     // nsteps_all time steps, every one of them with a barrier that every wavefront of the block joins
-    const int nsteps = g.nz + (RES ? DR : NP);
+    const int nsteps = g.nz + (RST ? DR + 2 : RES ? DR : NP); // RST: the last coarse plane follows two steps later
     const int nsteps_all = nsteps + (STAGES - 1) * LAG;
     // One group of UN consecutive time steps, unrolled so that every ring index is a constant.
     // FAST groups are those whose steps all work on planes strictly between the z faces and below
@@ -324,6 +380,8 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
         desc_t d_in = plane_desc(inb + slab * (i0 + PD), in_bytes), d_f = plane_desc(f + slab * (i0 + PD), plane_bytes);
         desc_t d_out = plane_desc(out + slab * (i0 - NP), plane_bytes);
         desc_t d_res = plane_desc(RES ? res + slab * (i0 - DR) : out, plane_bytes);
+        // coarse plane written at the group's first step: fine plane i0 - 2 - DR is its centre
+        desc_t d_rc = plane_desc(RST ? rcb + cf.slab * ((i0 - 2 - DR) / 2) : (R *)out, rcplane_bytes);
         // coarse plane prefetched at the group's first (even) step: the upper one of fine plane i0 + PD
         desc_t d_e = plane_desc(COR ? eb + cf.slab * ((i0 + PD) / 2 + 1) : eb, cplane_bytes);
         desc_t d_k = plane_desc(MAP ? g.cells + slab * (i0 + PD) : (const unsigned char *)f, cells_bytes);
@@ -545,6 +603,42 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                     for (int r = 0; r < SR; ++r)
                         buf_store_hidden(((r & 1) ^ s0) ? C[1][PH(NP)][r / 2] : C[0][PH(NP)][r / 2], ro, soff[r]);
                 }
+                // ---- restriction: coarse plane (i - 2 - DR) / 2, whose upper fine plane got its residual in
+                // the step before (every second step) ------------------------------------------------
+#define RSLOT(k) ((((u) - DR - (k)) % 2 + 2) % 2 ? (((((u) - DR - (k)) % UN + UN) % UN) >> 1) & 1 : 2) /* slot of plane i - DR - k */
+                if constexpr (RST) {
+                    // the pair below this strip's last pair, of the plane the step before left
+                    Rr[RSLOT(1)][0][J] = rbn[par ^ 1][wd][0][lane];
+                    Rr[RSLOT(1)][1][J] = rbn[par ^ 1][wd][1][lane];
+                    const int zc = i - 2 - DR; // centre plane
+                    if (((u + 1 + DR) & 1) != 0 && (FAST || (zc >= 0 && zc <= zlast))) {
+                        const bool zface = zc <= 0 || zc >= zlast;
+                        const desc_t rd = FAST ? d_rc : plane_desc(rcb + cf.slab * (zc / 2), rcplane_bytes);
+#pragma unroll
+                        for (int j = 0; j < J; ++j) {
+                            // planes z+ (P), z (Z), z- (M); colour 0 (A) holds the rows of the coarse points on
+                            // even lanes and the rows below them on odd lanes, colour 1 (B) the other way round
+#define RA(k, jj) Rr[RSLOT(k)][0][jj]
+#define RB(k, jj) Rr[RSLOT(k)][1][jj]
+#define UP(v) from_upper_lane(v)
+#define LO(v) from_lower_lane(v)
+                            // mg_1.cl:162-189, term by term
+                            const R corners = UP(RA(1, j + 1)) + LO(RA(1, j + 1)) + UP(RA(1, j)) + LO(RA(1, j)) +
+                                              UP(RA(3, j + 1)) + LO(RA(3, j + 1)) + UP(RA(3, j)) + LO(RA(3, j));
+                            const R edges = UP(RA(2, j + 1)) + LO(RA(2, j + 1)) + UP(RA(2, j)) + LO(RA(2, j)) +
+                                            RB(3, j + 1) + RB(3, j) + UP(RB(3, j)) + LO(RB(3, j)) +
+                                            RB(1, j + 1) + RB(1, j) + UP(RB(1, j)) + LO(RB(1, j));
+                            const R faces = RB(2, j + 1) + RB(2, j) + UP(RB(2, j)) + LO(RB(2, j)) + RA(1, j) + RA(3, j);
+                            R val = 1.0 / 64.0 * corners + 1.0 / 32.0 * edges + 1.0 / 16.0 * faces + 1.0 / 8.0 * (RA(2, j));
+                            asm("" : "+v"(val));
+                            buf_store_hidden(injl[j] || zface ? RA(2, j) : val, rd, cof[j]);
+#undef RA
+#undef RB
+#undef UP
+#undef LO
+                        }
+                    }
+                }
                 // ---- residual of plane i - DR, whose neighbours are all final ---------------------
                 if (RES) {
                     const int z = i - DR;
@@ -576,17 +670,28 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                             }
                         }
                         const desc_t rr = FAST ? d_res : plane_desc(res + slab * z, plane_bytes);
+                        if constexpr (RST) {
+                            // keep the plane, hand its first pair to the strip above, write the seam rows
 #pragma unroll
-                        for (int r = 0; r < SR; ++r)
-                            buf_store_hidden(((r & 1) ^ s0) ? rv[1][r / 2] : rv[0][r / 2], rr, soff[r]);
+                            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                                for (int j = 0; j < J; ++j) Rr[RSLOT(0)][c][j] = rv[c][j];
+                                rbn[par][w][c][lane] = rv[c][0];
+                            }
+                            buf_store_hidden(((RS0 & 1) ^ s0) ? rv[1][RS0 / 2] : rv[0][RS0 / 2], rr, rof[0]);
+                            buf_store_hidden(((RS1 & 1) ^ s0) ? rv[1][RS1 / 2] : rv[0][RS1 / 2], rr, rof[1]);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < SR; ++r)
+                                buf_store_hidden(((r & 1) ^ s0) ? rv[1][r / 2] : rv[0][r / 2], rr, soff[r]);
+                        }
                     }
                 }
+#undef RSLOT
 #undef PH
                 if (FAST) {
                     MGRT_STAMP(4); // stores / hand-over (and the residual pass)
-#ifdef MGRT_STAMPS
-                    acc[7] += 1;
-#endif
+                    MGRT_STAMP_STEP();
                 }
                 if (FAST && (FIRST || LAST)) {
                     if (MAP)
@@ -594,6 +699,8 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                     advance(d_in, slab_bytes), advance(d_f, slab_bytes), advance(d_out, slab_bytes);
                     if (RES)
                         advance(d_res, slab_bytes);
+                    if (RST && ((u + 1 + DR) & 1) != 0)
+                        advance(d_rc, (unsigned long long)cf.slab * sizeof(R));
                     if (COR && (u & 1) == 0)
                         advance(d_e, (unsigned long long)cf.slab * sizeof(R));
                 }
@@ -641,11 +748,7 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
             drain();
         }
     }
-#ifdef MGRT_STAMPS
-    if (blockIdx.x == gridDim.x / 2 && lane == 0)
-        for (int k = 0; k < 8; ++k)
-            mgrt_stamps[wave & 15][k] = acc[k];
-#endif
+    MGRT_STAMP_END(wave, lane);
     }; // march
 
     if constexpr (STAGES == 1) {
@@ -658,11 +761,12 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     }
 }
 
-template <class R, int ITERS, int SR, int NW, int PD, bool RES = false, bool COR = false, int STAGES = 1, bool MAP = false>
+template <class R, int ITERS, int SR, int NW, int PD, bool RES = false, bool COR = false, int STAGES = 1, bool MAP = false,
+          bool RST = false>
 mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, int zcount, hipStream_t hs,
-                   R *res = nullptr, const mgrt_grid *cg = nullptr, const R *e = nullptr)
+                   R *res = nullptr, const mgrt_grid *cg = nullptr, const R *e = nullptr, R *rc = nullptr)
 {
-    constexpr int H = 2 * ITERS * STAGES + (RES ? 1 : 0), OX = kWave - 2 * H, OY = NW * SR - 2 * H;
+    constexpr int H = 2 * ITERS * STAGES + (RES ? 1 : 0), OX = kWave - 2 * (H + (RST ? 1 : 0)), OY = NW * SR - 2 * H;
     static_assert(OY > 0, "tile has no interior");
     static_assert(NW * STAGES * kWave <= 1024, "block too large");
     // every strip starts on an even row of its slab (the corrected input relies on it)
@@ -670,14 +774,14 @@ mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega,
     const int ntx = (g->nx + OX - 1) / OX, nty = (g->ny + OY - 1) / OY;
     const dim3 grid(ntx * nty);
     CoarseField cf = {};
-    if (COR) {
-        cf.e = e, cf.pitch = cg->pitch, cf.slab = cg->slab;
+    if (COR || RST) {
+        cf.e = e, cf.rc = rc, cf.pitch = cg->pitch, cf.slab = cg->slab;
         cf.nx = cg->nx, cf.ny = cg->ny, cf.nz = cg->nz, cf.y0 = cg->y0;
     }
     if (omega == (R)1)
-        k_smooth3d_fused<R, ITERS, SR, NW, PD, true, RES, COR, STAGES, MAP><<<grid, NW * STAGES * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
+        k_smooth3d_fused<R, ITERS, SR, NW, PD, true, RES, COR, STAGES, MAP, RST><<<grid, NW * STAGES * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
     else
-        k_smooth3d_fused<R, ITERS, SR, NW, PD, false, RES, COR, STAGES, MAP><<<grid, NW * STAGES * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
+        k_smooth3d_fused<R, ITERS, SR, NW, PD, false, RES, COR, STAGES, MAP, RST><<<grid, NW * STAGES * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
     MGRT_HIP(hipGetLastError());
     return MGRT_OK;
 }
@@ -805,7 +909,7 @@ mgrt_status correct_smooth_sweep(const mgrt_grid *fine, const mgrt_grid *coarse,
 // out = S^iters(in) and rc = Restrict(f - A out): the pre-smoother with everything the coarse level
 // needs from this one.
 template <class R>
-mgrt_status smooth_sweep_residual_restrict(const mgrt_grid *fine, const mgrt_grid *coarse, R *out, R *rc, const R *in,
+mgrt_status smooth_sweep_residual_restrict(const mgrt_grid *fine, const mgrt_grid *coarse, R *out, R *rc, R *r, const R *in,
                                            const R *f, R omega, int iters, int zcount, mgrt_stream s)
 {
     const char *who = "mgrt_smooth_sweep_residual_restrict";
@@ -824,36 +928,53 @@ mgrt_status smooth_sweep_residual_restrict(const mgrt_grid *fine, const mgrt_gri
         return fail(MGRT_E_UNSUPPORTED, "%s: the first-order Neumann condition is in mgrt_smooth_pass only", who);
     if (iters != 1 && iters != 2)
         return fail(MGRT_E_UNSUPPORTED, "%s: iters must be 1 or 2, got %d", who, iters);
-    if (fine->dim != 2 || fine->nx % 2 == 0 || fine->ny % 2 == 0)
-        return fail(MGRT_E_UNSUPPORTED, "%s: 2D grids with odd extents only", who);
+    if (fine->nx % 2 == 0 || fine->ny % 2 == 0)
+        return fail(MGRT_E_UNSUPPORTED, "%s: grids with odd extents only", who);
     if (fine->y0 != 0 || fine->ny != fine->gny || coarse->y0 != 0 || coarse->ny != coarse->gny)
         return fail(MGRT_E_UNSUPPORTED, "%s: whole grids only, not y-slabs", who);
-    return smooth_sweep_2d(fine, coarse, out, rc, in, nullptr, f, omega, iters, (hipStream_t)s);
+    if (fine->dim == 2)
+        return smooth_sweep_2d(fine, coarse, out, rc, in, nullptr, f, omega, iters, (hipStream_t)s);
+    MGRT_REQUIRE(coarse->nz == (fine->nz + 1) / 2, "%s: coarse grid has %d planes for %d", who, coarse->nz, fine->nz);
+    if (!restrict_sweep_3d_supported(fine, sizeof(R), iters))
+        return fail(MGRT_E_UNSUPPORTED, "%s: in 3D, whole grids with odd extents and more than 300^2 columns, 4-byte "
+                                        "elements and iters == 2 only", who);
+    MGRT_REQUIRE(r && r != out && r != rc && r != in && r != f, "%s: in 3D, r must be a work array of its own", who);
+    if constexpr (sizeof(R) == 4) {
+        // The sweep forms every coarse row except the one on each seam between two rows of tiles; it leaves
+        // the three fine residual rows around such a seam in r, and the restriction of those coarse rows
+        // alone follows.
+        constexpr int SR = 4, NW = 8, H = 5, OY = NW * SR - 2 * H;
+        if (mgrt_status st = launch<R, 2, SR, NW, 4, true, false, 1, false, true>(fine, out, in, f, omega, zcount, (hipStream_t)s, r,
+                                                                                 coarse, nullptr, rc))
+            return st;
+        const int nseams = (fine->ny + OY - 1) / OY - 1;
+        return restrict_rows(fine, coarse, rc, r, OY / 2, OY / 2, nseams, (hipStream_t)s);
+    }
+    return fail(MGRT_E_UNSUPPORTED, "%s: no 3D kernel for this element size", who);
 }
 
 } // namespace
 
-#ifdef MGRT_STAMPS
-extern "C" mgrt_status mgrt_debug_stamps(unsigned long long *out)
-{
-    MGRT_HIP(hipDeviceSynchronize());
-    MGRT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(mgrt_stamps), sizeof(unsigned long long) * 16 * 8));
-    return MGRT_OK;
-}
-#endif
-
 extern "C" mgrt_status mgrt_smooth_sweep_residual_restrict_f32(const mgrt_grid *fine, const mgrt_grid *coarse, float *out,
-                                                               float *rc, const float *in, const float *f, float omega,
-                                                               int iters, int zcount, mgrt_stream s)
+                                                               float *rc, float *r, const float *in, const float *f,
+                                                               float omega, int iters, int zcount, mgrt_stream s)
 {
-    return smooth_sweep_residual_restrict<float>(fine, coarse, out, rc, in, f, omega, iters, zcount, s);
+    return smooth_sweep_residual_restrict<float>(fine, coarse, out, rc, r, in, f, omega, iters, zcount, s);
 }
 
 extern "C" mgrt_status mgrt_smooth_sweep_residual_restrict_f64(const mgrt_grid *fine, const mgrt_grid *coarse, double *out,
-                                                               double *rc, const double *in, const double *f, double omega,
-                                                               int iters, int zcount, mgrt_stream s)
+                                                               double *rc, double *r, const double *in, const double *f,
+                                                               double omega, int iters, int zcount, mgrt_stream s)
 {
-    return smooth_sweep_residual_restrict<double>(fine, coarse, out, rc, in, f, omega, iters, zcount, s);
+    return smooth_sweep_residual_restrict<double>(fine, coarse, out, rc, r, in, f, omega, iters, zcount, s);
+}
+
+extern "C" int mgrt_smooth_sweep_residual_restrict_supported(const mgrt_grid *fine, int elem_size, int iters)
+{
+    if (!fine || fine->cells || (iters != 1 && iters != 2) || (elem_size != 4 && elem_size != 8) || neumann_extension(fine) ||
+        fine->nx % 2 == 0 || fine->gny % 2 == 0 || fine->y0 != 0 || fine->ny != fine->gny)
+        return 0;
+    return fine->dim == 2 || restrict_sweep_3d_supported(fine, (size_t)elem_size, iters);
 }
 
 extern "C" int mgrt_correct_smooth_sweep_supported(const mgrt_grid *fine, int elem_size, int iters)

@@ -169,6 +169,7 @@ mgrt_plan *SolverCore::planFor(const Dims &n)
     d.no_fuse = 0;
     d.no_bottom = 0;
     d.neumann = 0;
+    d.separate_restrict = 0;
     const mgrt_grid top = describe(n);
     for (int i = 0; i < 6; ++i)
         d.face[i] = top.face[i];

@@ -741,3 +741,69 @@ def test_argument_errors(dev):
         L.smooth_pass(g, u, u, 1.0, 0)
     with pytest.raises(L.MgrtError):
         L.Plan((6, 6, 6), torch.float32)
+
+
+# 3D shapes (nz, ny, nx) above the 300^2-column limit of the bandwidth-bound sweeps: one tile row seam
+# falling on the grid's last row (ny - 1 a multiple of the 22 rows a tile row owns), a last tile row of
+# a single grid row, several tiles in x with a narrow last one, the smallest plane count.
+RST_SHAPES = [(9, 331, 305), (5, 309, 311), (21, 353, 321)]
+
+
+@pytest.mark.parametrize("shape", RST_SHAPES, ids=lambda s: "x".join(map(str, s[::-1])))
+def test_3d_sweep_with_restriction_matches_oracle(dev, mgo, shape):
+    """mgrt_smooth_sweep_residual_restrict in 3D: the pre-smoother that hands the coarse level its
+    right-hand side, against smoother passes + residual_kernel + reduction_kernel of the oracle
+    (mg_1.cl:56-104, 111-133, 146-190), bit for bit: Dirichlet and mixed faces, omega 1 and not,
+    both z ranges of the smoother, a zero start given as NULL."""
+    import torch
+    from multigrid_amd import _lib as L
+    dt = np.float32
+    rng = np.random.default_rng(1234 + shape[1])
+    cs = tuple((s + 1) // 2 for s in shape)
+    for faces in ((2,) * 6, (2, 3, 3, 2, 2, 3), (3, 2, 2, 3, 3, 2)):
+        cell = mgo.box_cells(shape, faces)
+        g, gc = L.grid(shape, faces=faces), L.grid(cs, faces=faces)
+        assert L.restrict_sweep_supported(g, torch.float32, 2)
+        u = rng.standard_normal(shape).astype(dt)
+        f = rng.standard_normal(shape).astype(dt)
+        df = to_dev(f, dev)
+        for omega, zc, zero_start in ((1.0, None, False), (0.8, (shape[0] + 1) // 2, False), (1.0, None, True)):
+            a = np.zeros_like(u) if zero_start else u.copy()
+            for _ in range(2):
+                for odd in (0, 1):
+                    mgo.smooth_pass(cell, a, f, dt(omega), odd, zc)
+            r = np.zeros_like(u)  # cells the reference leaves unwritten count as 0
+            mgo.residual(cell, r, a, f)
+            want_c = np.empty(cs, dt)
+            mgo.restrict(cell, want_c, r)
+            du = None if zero_start else to_dev(u, dev)
+            got_u = torch.full(shape, 5.0, dtype=torch.float32, device=dev)
+            got_c = torch.full(cs, 4.0, dtype=torch.float32, device=dev)
+            work = torch.full(shape, 9.0, dtype=torch.float32, device=dev)
+            L.smooth_sweep_residual_restrict(g, gc, got_u, got_c, du, df, omega, 2, zc, r=work)
+            torch.cuda.synchronize()
+            assert bits_equal(got_u.cpu().numpy(), a), (shape, faces, omega, zc, "u")
+            gc_host = got_c.cpu().numpy()
+            if not bits_equal(gc_host, want_c):
+                bad = np.argwhere(gc_host.view(np.uint32) != want_c.view(np.uint32))
+                raise AssertionError((shape, faces, omega, zc, "rc", len(bad), bad[:8].tolist(),
+                                      sorted(set(bad[:, 1].tolist()))[:12], sorted(set(bad[:, 2].tolist()))[:12],
+                                      sorted(set(bad[:, 0].tolist()))[:12]))
+
+
+def test_plan_with_restriction_in_sweep_equals_separate_restriction(dev):
+    """A V(2,2) cycle whose finest level carries the restriction in the pre-smoothing sweep, against the
+    same plan with the restriction as a launch of its own: same bits."""
+    import torch
+    from multigrid_amd import _lib as L
+    shape = (33, 321, 321)
+    rng = np.random.default_rng(7)
+    f = to_dev(rng.standard_normal(shape).astype(np.float32), dev)
+    out = []
+    for sep in (False, True):
+        u = torch.zeros(shape, dtype=torch.float32, device=dev)
+        plan = L.Plan(shape, torch.float32, zfull=True, separate_restrict=sep)
+        plan.vcycle(u, f, 1.0, 2, 2, 1, 2)
+        plan.close()
+        out.append(u.cpu().numpy())
+    assert bits_equal(out[0], out[1])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a wavefront of the fused 3D sweep spends a time step: runs one sweep on a diagnostic build of
-the library (make stamps -> multigrid_amd/libmgrt_stamps.so, compiled with -DMGRT_STAMPS) and prints,
+the library (make stamps -> multigrid_amd/libmgrt_stamps.so, the kernel source with the stamp hooks of tools/diag/mgrt_stamps.hip) and prints,
 for every wavefront of the middle block, shader-clock cycles per fast step and segment.
 usage: tools/stamps.py [--n 257] [--iters 2] [--res]"""
 import argparse
