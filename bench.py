@@ -56,20 +56,31 @@ def make_problem(shape, dtype, faces, device, rows=None):
     rows = (lo, hi): only those y rows of the 3D field (a rank's slab), the same values."""
     import math
     import torch
-    ax = [(torch.arange(n, device=device, dtype=dtype) / (n - 1)).double() for n in shape]
+    # Coordinates i/(n-1) in `real`, widened to double for the function bodies (M_PI makes them double).
+    # The sines and cosines of an axis are taken by the C library on the host, as the reference takes
+    # them, so that the field equals the oracle's bit for bit in either precision; the products follow the
+    # reference's left-to-right order and run on the device (IEEE double, no contraction between torch ops).
+    ax = [(torch.arange(n, dtype=dtype) / (n - 1)).double().tolist() for n in shape]
     ylo, yhi = rows if rows else (0, shape[-2])
     if rows:
-        ax[1] = ax[1][ylo:yhi]
+        ax[-2] = ax[-2][ylo:yhi]
+    pi = math.pi
+
+    def on_axis(fn, axis):
+        t = torch.tensor([fn(c) for c in ax[axis]], dtype=torch.float64, device=device)
+        return t.reshape([-1 if a == axis else 1 for a in range(len(shape))])
+
     if len(shape) == 3:
-        s = [torch.sin(math.pi * a) for a in ax]
-        sol = s[0][:, None, None] * s[1][None, :, None] * s[2][None, None, :]
-        rhs = (-3.0 * math.pi * math.pi) * sol
+        sz, sy, sx = (on_axis(lambda c: math.sin(pi * c), a) for a in range(3))
+        sol = sx * sy * sz                          # tridimS1: sin(pi x) * sin(pi y) * sin(pi z)
+        rhs = (-3.0 * pi * pi) * sx * sy * sz       # tridimF1: -3.0 * M_PI * M_PI * sin * sin * sin
     else:
-        y, x = ax[0][:, None], ax[1][None, :]
-        sol = torch.sin(26 * math.pi * x) + torch.cos(50 * math.pi * y) + torch.sin(math.pi * x)
-        rhs = -26 * 26 * math.pi ** 2 * torch.sin(26 * math.pi * x) - 50 * 50 * math.pi ** 2 * torch.cos(50 * math.pi * y) \
-            - math.pi ** 2 * torch.sin(math.pi * x)
-        rhs = rhs.expand(shape)
+        s26 = on_axis(lambda c: math.sin(26 * pi * c), 1)
+        c50 = on_axis(lambda c: math.cos(50 * pi * c), 0)
+        s1 = on_axis(lambda c: math.sin(pi * c), 1)
+        # sinfunc2sol spells its arguments M_PI*26*x and M_PI*50*y: the same doubles, 26 and 50 being exact
+        sol = (s26 + c50 + s1).expand(len(ax[0]), len(ax[1]))
+        rhs = ((-26 * 26 * pi * pi) * s26 - (50 * 50 * pi * pi) * c50 - (pi * pi) * s1).expand(len(ax[0]), len(ax[1]))
     ny = shape[-2]
     dh = torch.tensor(1.0 / (shape[-1] - 1), dtype=dtype, device=device)
     f = rhs.to(dtype) * dh * dh
@@ -117,9 +128,10 @@ def cpu_threads():
     return max(1, n)
 
 
-def cpu_baseline(name, budget_s=12.0):
+def cpu_baseline(name, shape=None, budget_s=12.0):
     """The oracle's C restatement (oracle/libmg_oracle.so, OpenMP) timed on this host on the same
-    extents, dtype and problem: V(2,2) cycles from a zero guess for about `budget_s` seconds."""
+    extents (`shape` when --n overrides the configuration's), dtype and problem: V(2,2) cycles from a
+    zero guess for about `budget_s` seconds."""
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -127,9 +139,14 @@ def cpu_baseline(name, budget_s=12.0):
     o = _oracle.load("mgo")
     if o is None:
         return None
-    shape, dt, faces, problem, _ = CONFIGS[name]
+    cfg_shape, dt, faces, problem, _ = CONFIGS[name]
+    shape = tuple(shape) if shape else cfg_shape
     npdt = np.float32 if dt == "f32" else np.float64
     threads = cpu_threads()
+    share = ""
+    if "OMP_NUM_THREADS" in os.environ and threads < len(os.sched_getaffinity(0)):
+        share = "; %d threads = this job's share of the host (OMP_NUM_THREADS), whose affinity mask shows %d CPUs" % (
+            threads, len(os.sched_getaffinity(0)))
     o.set_num_threads(threads)
     if faces != (D_,) * 6:
         # frozen faces: a callback per point would dominate, and their cells are never touched, so the
@@ -149,8 +166,8 @@ def cpu_baseline(name, budget_s=12.0):
     dt_s = (time.perf_counter() - t0) / reps
     dof = float(np.prod(shape))
     return {"value": dof / dt_s, "unit": "DOF/s", "cores": threads, "kind": "port",
-            "sample": "%d V(2,2) cycles of the same problem at %s (%s, full-z), %.3f s each%s"
-                      % (reps, "x".join(map(str, shape)), dt, dt_s, note)}
+            "sample": "%d V(2,2) cycles of the same problem at %s (%s, full-z), %.3f s each%s%s"
+                      % (reps, "x".join(map(str, shape)), dt, dt_s, note, share)}
 
 
 def spawn_ranks(args, argv):
@@ -175,8 +192,12 @@ ATTEMPTS = (
     ("RCCL, direct launches, the line's own workload only", ["--no-graph", "--no-weak"]),
     ("host callbacks over gloo, the line's own workload only", ["--no-graph", "--no-weak", "--transport", "gloo"]),
 )
-PHASE_LIMIT_S = {"start": 420.0}  # the first import of torch on a fresh box pages the image in
 PHASE_LIMIT_DEFAULT_S = float(os.environ.get("MGRT_BENCH_PHASE_LIMIT_S", "150"))
+# "start": the first import of torch on a fresh box pages the image in.  "imported": the rendezvous of an
+# attempt.  A rank whose worker died early in the attempt before arrives there at once and must outwait the
+# ranks that first have to notice their own hang (one phase limit) and then import (one start limit): with
+# anything shorter, import jitter decides whether that rank moves an attempt ahead of the others for good.
+PHASE_LIMIT_S = {"start": 420.0, "imported": 420.0 + 2 * PHASE_LIMIT_DEFAULT_S}
 
 
 def supervise(argv):
@@ -198,7 +219,7 @@ def supervise(argv):
                 child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker"] + argv + extra,
                                          env=env, stdout=out)
                 phase, since, why = "start", time.monotonic(), None
-                while child.poll() is None:
+                while child.poll() is None and phase != "done":
                     time.sleep(0.25)
                     now = open(phase_file).read().split()
                     if now and now[-1] != phase:
@@ -209,11 +230,18 @@ def supervise(argv):
                         child.wait()
                         break
                 now = open(phase_file).read().split()
-                if now and now[-1] == "done":  # the result is out; how the process ended after that is not the bench's business
+                if now and now[-1] == "done":
+                    # The result is out: pass it on now.  How the process ends after that (closing the process
+                    # group, unloading the GPU runtime) is not the bench's business and gets a few seconds.
                     out.seek(0)
                     for line in out:  # the result line to stdout; what libraries printed there goes to stderr
                         (sys.stdout if line.startswith("{") else sys.stderr).write(line)
                     sys.stdout.flush()
+                    try:
+                        child.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        child.kill()
+                        child.wait()
                     return 0
                 why = why or "worker left with status %s in phase '%s'" % (child.returncode, now[-1] if now else "start")
         failures.append("%s: %s" % (what, why))
@@ -315,7 +343,7 @@ def main():
             dist.all_reduce(sync.cpu())
             torch.cuda.synchronize()
 
-    layout, weak, big = None, None, None
+    layout, weak, big, spread = None, None, None, None
     if world > 1:
         # mgrt_slab_plan: this rank's slab, halos over RCCL on the plan's stream, a cycle per graph launch.
         # torch.distributed (gloo) only hands the RCCL id round and closes the timed region.
@@ -422,6 +450,18 @@ def main():
             barrier()
             dt = time.perf_counter() - t0
             r1 = plan.vcycle(u, f, ncycles=0, history=True)[0]
+            # Outside the timed region: the same number of cycles again, every one between its own pair of
+            # events on the stream it runs on, for the spread over the steps.
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+            marks[0].record(stream)
+            for k in range(args.steps):
+                plan.vcycle(u, f, 1.0, 2, 2, 1, 1)
+                marks[k + 1].record(stream)
+            marks[-1].synchronize()
+            each = sorted(a.elapsed_time(b) for a, b in zip(marks, marks[1:]))
+            if each:
+                spread = {"min": each[0], "median": each[len(each) // 2], "max": each[-1], "steps": len(each),
+                          "what": "every cycle between its own events, a second run of the same steps after the timed region"}
             plan.close()
 
         if rank == 0:
@@ -440,12 +480,24 @@ def main():
                 alg_bytes = (3.0 * dof + float(rc.numel())) * w
                 kernel = ("k_smooth2d_cols", "2D sweep of 2 red-black iterations that also writes the restricted residual")
                 fields = {0: "float" if w == 4 else "double", 1: "2", 5: "2"}
-            elif w == 4 and shape[1] * shape[2] > 300 * 300:
-                resid = torch.empty_like(u)
-                launch = lambda a, b: _lib.smooth_sweep_residual(g, a, resid, b, f, 1.0, 2)
-                alg_bytes = 4.0 * dof * w  # read u, read f, write the smoothed field, write the residual
-                kernel = ("k_smooth3d_fused", "3D sweep of 2 red-black iterations with the residual pass")
-                fields = {0: "float", 1: "2", 5: "true", 6: "true", 7: "false"}
+            elif w == 4 and _lib.restrict_sweep_supported(g, tdt, 2):
+                # the headline workload: the sweep also forms the residual and restricts it to the coarse grid
+                cshape = tuple((s + 1) // 2 for s in shape)
+                gc = _lib.grid(cshape, faces=faces)
+                rc = torch.empty(cshape, dtype=tdt, device=dev)
+                ec = torch.zeros(cshape, dtype=tdt, device=dev)
+                resid = torch.empty_like(u)  # only the rows next to tile seams pass through it
+
+                def part(mask, a, b):  # the operation is two launches: 1 = the sweep kernel, 2 = the seam rows' restriction
+                    _lib.sweep_parts(mask)
+                    try:
+                        _lib.smooth_sweep_residual_restrict(g, gc, a, rc, b, f, 1.0, 2, r=resid)
+                    finally:
+                        _lib.sweep_parts(3)
+                launch = lambda a, b: part(1, a, b)
+                alg_bytes = (3.0 * dof + float(rc.numel())) * w  # read u, read f, write the smoothed field, write the coarse rhs
+                kernel = ("k_smooth3d_fused", "3D sweep of 2 red-black iterations with the residual pass and its restriction")
+                fields = {0: "float", 1: "2", 5: "true", 6: "true", 7: "false", 10: "true"}
             else:
                 launch = lambda a, b: _lib.smooth_sweep(g, a, b, f, 1.0, 2)
                 alg_bytes = 3.0 * dof * w  # read u, read f, write the smoothed field
@@ -455,32 +507,38 @@ def main():
                     fields.update({1: "1", 8: "2"})  # latency-bound level: two stages of one iteration each
             # Every launch between its own pair of events on the stream it runs on, after a few untimed ones
             # (the first launches on freshly allocated arrays run 10-30 % long).  For the headline workload the
-            # launches that follow the sweep on the finest level of a cycle are issued in between (restriction,
-            # the sweep on the corrected field), so that the sweep finds memory as it does in the cycle.
+            # launches that follow the sweep on the finest level of a cycle are issued in between (the seam rows'
+            # restriction, the sweep on the corrected field), so that the sweep finds memory as it does in the
+            # cycle; a third event after them closes the finest level's share of a cycle.
             follow = None
-            if kernel[1].endswith("residual pass"):
-                cshape = tuple((s + 1) // 2 for s in shape)
-                gc = _lib.grid(cshape, faces=faces)
-                rc = torch.empty(cshape, dtype=tdt, device=dev)
-                ec = torch.zeros(cshape, dtype=tdt, device=dev)
-
+            if kernel[1].endswith("its restriction"):
                 def follow(a, b):  # a: the smoothed field just written, b: the array the cycle continues in
-                    _lib.restrict(g, gc, rc, resid)
+                    part(2, a, b)
                     _lib.correct_smooth_sweep(g, gc, b, a, ec, f, 1.0, 2)
             reps, warm = (20, 5) if dof < 6e8 else (6, 2)
             pairs = []
             for i in range(warm + reps):
                 a, b = (work, u) if follow or i % 2 == 0 else (u, work)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 e0.record(stream)
                 launch(a, b)
                 e1.record(stream)
                 if follow:
                     follow(a, b)
-                pairs.append((e0, e1))
-            pairs[-1][1].synchronize()
+                    e2.record(stream)
+                pairs.append((e0, e1, e2))
+            pairs[-1][2 if follow else 1].synchronize()
             torch.cuda.synchronize()
-            t_kernel = sum(x.elapsed_time(y) for x, y in pairs[warm:]) * 1e-3 / reps
+            t_kernel = sum(x.elapsed_time(y) for x, y, _ in pairs[warm:]) * 1e-3 / reps
+            level0 = None
+            if follow:
+                t_l0 = sum(x.elapsed_time(z) for x, _, z in pairs[warm:]) * 1e-3 / reps
+                l0_bytes = 2.0 * (3.0 * dof + float(rc.numel())) * w
+                level0 = {"ms": t_l0 * 1e3, "compulsory_bytes": l0_bytes, "achieved": l0_bytes / t_l0 / 1e9, "unit": "GB/s",
+                          "frac": l0_bytes / t_l0 / 1e9 / HBM_PEAK_GBS,
+                          "what": "the finest level's three launches of a cycle back to back between events: sweep x2 with "
+                                  "residual and restriction (u, f in; u, coarse rhs out), the seam rows' restriction, sweep x2 "
+                                  "on u + 4 P(e) (u, e, f in; u out); every field counted once per launch that needs it"}
 
     if rank == 0:
         achieved = alg_bytes / t_kernel / 1e9
@@ -505,7 +563,7 @@ def main():
             **({"rehearsal": "%d ranks on %d GPU(s) over gloo: not a measurement" % (world, ndev)} if rehearse else {}),
             "config": {"workload": "%s, V(2,2), omega=1%s" % (workload, ", smoother over all z planes" if len(shape) == 3 else ""),
                        "name": args.config, "levels": len(sizes), "graph": not args.no_graph,
-                       "parallelism": "single GPU" if world == 1 else "%d y-slabs, RCCL halo exchange" % world,
+                       "parallelism": "single GPU" if world == 1 else "%d y-slabs, halo exchange: %s" % (world, note[0]),
                        "layout": layout,
                        "residual_before": r0, "residual_after_warmup_and_steps": r1},
             "vcycles_per_s": args.steps / dt,
@@ -516,11 +574,13 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_s": t_kernel},
+            **({"level0": level0} if level0 else {}),
+            **({"step_ms": spread} if spread else {}),
         }
         if world == 1 and not args.no_cpu:
             del f, u, work
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(args.config if not args.n else args.config)
+            out["cpu_baseline"] = cpu_baseline(args.config, shape)
         if os.environ.get("MGRT_BENCH_EARLIER"):
             out["config"]["attempts_that_failed"] = os.environ["MGRT_BENCH_EARLIER"]
         print(json.dumps(out), flush=True)

@@ -108,6 +108,13 @@ int mgrt_correct_smooth_sweep_supported(const mgrt_grid *fine, int elem_size, in
 /* The same question for mgrt_smooth_sweep_residual_restrict_f32/_f64. */
 int mgrt_smooth_sweep_residual_restrict_supported(const mgrt_grid *fine, int elem_size, int iters);
 
+/* Measurement aid, no counterpart in the reference.  mgrt_smooth_sweep_residual_restrict_f32 in 3D is two
+ * launches (the sweep, then the restriction of the coarse rows on its tile seams); a harness that times
+ * the sweep kernel alone between its own events selects with `mask` which of them the following calls of
+ * this process issue: bit 0 the sweep, bit 1 the seam restriction.  Returns the previous mask; the
+ * default, 3, is the only setting that computes the documented result. */
+int mgrt_sweep_parts(int mask);
+
 #define MGRT_DECLARE_KERNELS(R, S)                                                                 \
     /* One colour pass of the weighted Gauss-Seidel smoother, in place.  Replaces                 \
        iteration_kernel (mg_1.cl:91-104, mg_0.cl:86-98) as launched by smoother_iterate           \

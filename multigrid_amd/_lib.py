@@ -69,7 +69,7 @@ _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "u
             "stream_create", "stream_destroy", "sync", "zero", "box_cells_host",
             "plan_create", "plan_destroy", "plan_levels", "plan_level_dims", "plan_set_cells",
             "plan_vcycle", "plan_fmg", "correct_smooth_sweep_supported", "smooth_sweep_residual_restrict_supported",
-            "sumsq_noalloc_f32",
+            "sumsq_noalloc_f32", "sweep_parts",
             "rccl_unique_id", "rccl_selftest", "slab_plan_create", "slab_plan_destroy", "slab_plan_distributed_levels",
             "slab_plan_uses_graph", "slab_plan_rows", "slab_plan_vcycle", "slab_plan_fmg"]
 SYMBOLS = ["mgrt_" + n for n in _RUNTIME] + ["mgrt_%s_%s" % (k, s) for k in _KERNELS for s in ("f32", "f64")]
@@ -119,6 +119,8 @@ def load():
     for name in ("slab_plan_distributed_levels", "slab_plan_uses_graph"):
         getattr(lib, "mgrt_" + name).restype = i
         getattr(lib, "mgrt_" + name).argtypes = [p]
+    lib.mgrt_sweep_parts.restype = i
+    lib.mgrt_sweep_parts.argtypes = [i]
     lib.mgrt_correct_smooth_sweep_supported.restype = i
     lib.mgrt_correct_smooth_sweep_supported.argtypes = [G, i, i]
     lib.mgrt_smooth_sweep_residual_restrict_supported.restype = i
@@ -245,6 +247,12 @@ def smooth_sweep_residual_restrict(fine, coarse, out, rc, inp, f, omega, iters, 
     """r: 3D only, a work array of the fine grid's size (the fine residual next to tile seams passes through it)."""
     check(_fn("smooth_sweep_residual_restrict", f)(C.byref(fine), C.byref(coarse), _p(out), _p(rc), _p(r), _p(inp), _p(f),
                                                      omega, iters, fine.nz if zcount is None else zcount, _stream(stream)))
+
+
+def sweep_parts(mask):
+    """mgrt_sweep_parts: which launches of the two-launch 3D sweep with restriction are issued (bit 0 the sweep,
+    bit 1 the seam restriction); returns the previous mask.  For timing a kernel alone."""
+    return load().mgrt_sweep_parts(mask)
 
 
 def smooth_sweep_residual(g, out, r, inp, f, omega, iters, zcount=None, stream=None):

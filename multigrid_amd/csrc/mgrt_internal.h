@@ -31,6 +31,7 @@ struct Runtime {
     int device = -1;
     int num_cu = 0;
     double *static_partials = nullptr; // device address of the fixed scratch array of mgrt_sumsq_noalloc_f32
+    int sweep_parts = 3;               // mgrt_sweep_parts: which launches of a two-launch sweep operation are issued
 };
 Runtime &runtime();
 mgrt_status require_init();

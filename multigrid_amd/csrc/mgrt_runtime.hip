@@ -139,6 +139,14 @@ mgrt_status mgrt_shutdown(void)
     return MGRT_OK;
 }
 
+int mgrt_sweep_parts(int mask)
+{
+    Runtime &rt = runtime();
+    const int before = rt.sweep_parts;
+    rt.sweep_parts = mask & 3;
+    return before;
+}
+
 mgrt_status mgrt_device_name(char *buf, int len)
 {
     if (mgrt_status st = require_init())

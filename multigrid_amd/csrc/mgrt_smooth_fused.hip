@@ -944,11 +944,13 @@ mgrt_status smooth_sweep_residual_restrict(const mgrt_grid *fine, const mgrt_gri
         // the three fine residual rows around such a seam in r, and the restriction of those coarse rows
         // alone follows.
         constexpr int SR = 4, NW = 8, H = 5, OY = NW * SR - 2 * H;
-        if (mgrt_status st = launch<R, 2, SR, NW, 4, true, false, 1, false, true>(fine, out, in, f, omega, zcount, (hipStream_t)s, r,
-                                                                                 coarse, nullptr, rc))
-            return st;
+        const int parts = runtime().sweep_parts; // both, unless a timing harness asked for one alone
+        if (parts & 1)
+            if (mgrt_status st = launch<R, 2, SR, NW, 4, true, false, 1, false, true>(fine, out, in, f, omega, zcount,
+                                                                                     (hipStream_t)s, r, coarse, nullptr, rc))
+                return st;
         const int nseams = (fine->ny + OY - 1) / OY - 1;
-        return restrict_rows(fine, coarse, rc, r, OY / 2, OY / 2, nseams, (hipStream_t)s);
+        return parts & 2 ? restrict_rows(fine, coarse, rc, r, OY / 2, OY / 2, nseams, (hipStream_t)s) : MGRT_OK;
     }
     return fail(MGRT_E_UNSUPPORTED, "%s: no 3D kernel for this element size", who);
 }

@@ -267,3 +267,20 @@ def test_bench_problem_of_a_slab_equals_the_rows_of_the_whole():
             for lo, hi in ((0, 7), (4, 13), (9, 17), (0, 17)):
                 part = bench.make_problem((9, 17, 9), dt, faces, torch.device("cpu"), rows=(lo, hi))
                 assert torch.equal(part, whole[:, lo:hi, :])
+
+
+@pytest.mark.parametrize("shape, problem", [((33, 33, 33), 0), ((17, 33, 65), 0), ((65, 65), 1), ((33, 129), 1)])
+@pytest.mark.parametrize("dtname", ["float32", "float64"])
+def test_bench_problem_equals_the_oracles_discretisation(shape, problem, dtname):
+    """bench.make_problem samples tridimF1 / sinfunc2 (programstate.cpp:84-94,114-122) as discretize_func
+    does (functionhandler.cpp:25-45,64-84): bit for bit the oracle's right-hand side in both precisions."""
+    import sys
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    mgo = _oracle.load("mgo")
+    npdt = np.dtype(dtname).type
+    want, _ = mgo.discretize(problem, shape, npdt)
+    got = bench.make_problem(shape, getattr(torch, dtname), (2,) * 6, torch.device("cpu")).numpy()
+    bits = np.uint32 if npdt is np.float32 else np.uint64
+    assert np.array_equal(got.view(bits), want.view(bits))

@@ -50,7 +50,7 @@ def main():
             e1.record(stream)
             e1.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / args.reps
-        print("%-28s %9.1f us  %8.1f GB/s  (%4.1f%% of 8 TB/s)" % (name, t * 1e6, nbytes / t / 1e9, nbytes / t / 8e10))
+        print("%-36s %9.1f us  %8.1f GB/s  (%4.1f%% of 8 TB/s)" % (name, t * 1e6, nbytes / t / 1e9, nbytes / t / 8e10))
 
     timeit("copy (torch)", lambda: o.copy_(u), 2 * N * w)
     timeit("smooth_pass", lambda: L.smooth_pass(g, u, f, 1.0, 0), 2 * N * w)
@@ -59,6 +59,15 @@ def main():
     timeit("smooth_sweep x2 omega.8", lambda: L.smooth_sweep(g, o, u, f, 0.8, 2), 3 * N * w)
     timeit("smooth_sweep+res x2", lambda: L.smooth_sweep_residual(g, o, r, u, f, 1.0, 2), 4 * N * w)
     timeit("smooth_sweep+res x1", lambda: L.smooth_sweep_residual(g, o, r, u, f, 1.0, 1), 4 * N * w)
+    if L.restrict_sweep_supported(g, dt, 2):
+        timeit("sweep+res+restrict x2 (2 launches)", lambda: L.smooth_sweep_residual_restrict(g, gc, o, rc, u, f, 1.0, 2, r=r),
+               (3 * N + Nc) * w)
+
+        def sweep_alone():
+            L.sweep_parts(1)
+            L.smooth_sweep_residual_restrict(g, gc, o, rc, u, f, 1.0, 2, r=r)
+            L.sweep_parts(3)
+        timeit("sweep+res+restrict x2 (sweep)", sweep_alone, (3 * N + Nc) * w)
     timeit("residual", lambda: L.residual(g, r, u, f), 3 * N * w)
     n2 = torch.zeros(1, device="cuda", dtype=torch.float64)
     timeit("residual+norm", lambda: L.residual(g, r, u, f, norm2=n2), 3 * N * w)
@@ -94,7 +103,7 @@ def bench2d(args, torch, L, dt, w):
             e1.record(stream)
             e1.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / args.reps
-        print("%-28s %9.1f us  %8.1f GB/s  (%4.1f%% of 8 TB/s)" % (name, t * 1e6, nbytes / t / 1e9, nbytes / t / 8e10))
+        print("%-36s %9.1f us  %8.1f GB/s  (%4.1f%% of 8 TB/s)" % (name, t * 1e6, nbytes / t / 1e9, nbytes / t / 8e10))
 
     timeit("2D smooth_sweep x2", lambda: L.smooth_sweep(g, o, u, f, 1.0, 2), 3 * N * w)
     timeit("2D sweep+res+restrict x2", lambda: L.smooth_sweep_residual_restrict(g, gc, o, rc, u, f, 1.0, 2), (3 * N + Nc) * w)

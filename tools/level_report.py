@@ -49,6 +49,7 @@ def main():
         rows = rows[:end + 1]
     agg = defaultdict(list)
     level = 0
+    seam_next = False
     for t0, t1, name in rows:
         m = re.search(r"(k_\w+)<([^>]*)>", name)
         if not m:
@@ -59,15 +60,22 @@ def main():
             res, cor = targs[6] == "true", targs[7] == "true"
             if cor:
                 level -= 1
+            rst = len(targs) > 10 and targs[10] == "true"  # <R, ITERS, SR, NW, PD, OMEGA1, RES, COR, STAGES, MAP, RST>
             iters = int(targs[1]) * (int(targs[8]) if len(targs) > 8 else 1)  # iterations per stage x stages
-            fam = "%ssweep x%d%s" % ("correct + " if cor else "", iters, " + residual" if res else "")
-            byts = (4 if res else 3) * pts[level] * w + (pts[level + 1] * w if cor else 0)
+            fam = "%ssweep x%d%s" % ("correct + " if cor else "", iters, " + residual + restrict" if rst else " + residual" if res else "")
+            byts = (3 if rst else 4 if res else 3) * pts[level] * w + (pts[level + 1] * w if cor or rst else 0)
+            seam_next = rst
         elif k == "k_residual3d_v":
             if targs[-1] == "true":     # with the norm: the history between cycles, level 0
                 agg[(0, "residual + norm (history)", 3 * pts[0] * w)].append(dur)
                 level = 0
                 continue
             fam, byts = "residual", 3 * pts[level] * w
+        elif k == "k_restrict" and seam_next:
+            # the coarse rows on the seams between the sweep's rows of tiles (22 fine rows each): three fine
+            # rows read and one coarse row written per seam
+            seams = (sizes[level] + 21) // 22 - 1
+            fam, byts = "restrict (seam rows)", seams * (3 * sizes[level] ** 2 + sizes[level + 1] ** 2) * w
         elif k == "k_restrict":
             fam, byts = "restrict", (pts[level] + pts[level + 1]) * w
         elif k == "k_interp3d_v":
@@ -78,6 +86,8 @@ def main():
         else:
             continue
         agg[(level, fam, byts)].append(dur)
+        if k != "k_smooth3d_fused":
+            seam_next = False
         if k == "k_restrict":
             level += 1
     print("3D %d^3, %d-byte elements; achieved = algorithmic bytes / mean kernel time; peak %.0f GB/s" % (n, w, PEAK))
@@ -87,7 +97,7 @@ def main():
         gbs = byts / mean / 1e3 if byts else 0.0
         print("%-5d %-8s %-34s %6d %10.1f %10.0f %6.1f%%" % (lv, "%d^3" % sizes[lv], fam, len(v), mean, gbs, 100 * gbs / PEAK))
     per_level = defaultdict(float)
-    cycles = max(1, len(agg.get((0, "restrict", (pts[0] + pts[1]) * w), [])))
+    cycles = max(1, max(len(v) for (lv, fam, _), v in agg.items() if lv == 0 and fam.startswith("restrict")))
     for (lv, fam, byts), v in agg.items():
         if "history" not in fam:
             per_level[lv] += sum(v) / cycles
