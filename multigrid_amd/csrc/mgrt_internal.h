@@ -107,13 +107,15 @@ inline bool correct_sweep_3d_supported(const mgrt_grid *g, size_t elem, int iter
 }
 
 // Whether mgrt_smooth_sweep_residual_restrict has a 3D kernel for this level (the restriction carried in
-// the residual-carrying sweep): whole bandwidth-bound analytic boxes with odd extents, 4-byte elements,
-// two iterations.
+// the residual-carrying sweep): whole analytic boxes with odd extents; two iterations on bandwidth-bound
+// levels with 4-byte elements, or no iteration at all (residual and restriction alone) with either
+// element size on any level.
 inline bool restrict_sweep_3d_supported(const mgrt_grid *g, size_t elem, int iters)
 {
-    return g->dim == 3 && elem == 4 && iters == 2 && !g->cells && g->y0 == 0 && g->ny == g->gny && g->nx % 2 == 1 &&
-           g->gny % 2 == 1 && g->nz % 2 == 1 && g->nz >= 5 && !latency_bound_level(*g) && plane_offsets_fit(g, elem) &&
-           !neumann_extension(g);
+    if (!(g->dim == 3 && !g->cells && g->y0 == 0 && g->ny == g->gny && g->nx % 2 == 1 && g->gny % 2 == 1 && g->nz % 2 == 1 &&
+          g->nz >= 5 && plane_offsets_fit(g, elem) && !neumann_extension(g)))
+        return false;
+    return iters == 0 || (iters == 2 && elem == 4 && !latency_bound_level(*g));
 }
 
 // Full-weighting restriction (mgrt_restrict) of `nrows` coarse rows j0, j0 + jstep, ... only.

@@ -202,6 +202,12 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
     const bool restrict_in_sweep =
         res_in_sweep && (L.g.dim == 2 || (!p->desc.separate_restrict &&
                                           mgrt_smooth_sweep_residual_restrict_supported(&L.g, (int)sizeof(R), n1 < a1 ? 2 : 1)));
+    // Where no sweep carries them, residual and restriction run as one march of their own on the
+    // bandwidth-bound 3D levels (on the others a march costs its step latency whatever it computes: 100 us
+    // against 54 us for the two kernels at 257^3).
+    const bool march_residual_restrict =
+        !p->desc.separate_restrict && !p->desc.no_fuse && recurses(L.g) && L.g.dim == 3 && !latency_bound_level(L.g) &&
+        mgrt_smooth_sweep_residual_restrict_supported(&L.g, (int)sizeof(R), 0);
     if (a1 > 0) {
         R *res = restrict_in_sweep ? (R *)p->lv[l + 1].rhs : res_in_sweep ? (R *)L.r : nullptr;
         if (mgrt_status st = smooth_steps<R>(p, L, cur, alt, f, omega, a1, n1, res, u_is_zero,
@@ -213,12 +219,20 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
         for (int k = 0; k < v; ++k) {
             // outer/Neumann cells of the residual are defined as 0 (the reference reads
             // uninitialised memory there)
-            if (!(res_in_sweep && k == 0))
-                if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, 0, L.g.ny, s))
+            const bool have_r = res_in_sweep && k == 0, have_rc = restrict_in_sweep && k == 0;
+            if (!have_r && !have_rc && march_residual_restrict) {
+                // residual and restriction as one march over u and f: the fine residual stays in registers
+                if (mgrt_status st = K<R>::sweep_res_restrict(&L.g, &C.g, nullptr, (R *)C.rhs, (R *)L.r, cur, f, omega, 0,
+                                                              zcount_of(p, L.g), s))
                     return st;
-            if (!(restrict_in_sweep && k == 0))
-                if (mgrt_status st = K<R>::restrict_(&L.g, &C.g, (R *)C.rhs, (const R *)L.r, 0, C.g.ny, s))
-                    return st;
+            } else {
+                if (!have_r)
+                    if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, 0, L.g.ny, s))
+                        return st;
+                if (!have_rc)
+                    if (mgrt_status st = K<R>::restrict_(&L.g, &C.g, (R *)C.rhs, (const R *)L.r, 0, C.g.ny, s))
+                        return st;
+            }
             if (mgrt_status st = iterate<R>(p, l + 1, (R *)C.e, (const R *)C.rhs, omega, a1, a2, v, true)) // zero_mem(i), :59
                 return st;
             // in place: same values as the out-of-place kernel followed by the handle swap (:70-72)

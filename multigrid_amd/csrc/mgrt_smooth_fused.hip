@@ -253,7 +253,8 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     constexpr int WB = STG * NW; // this stage's wavefronts in bnd
     // per step; the coarse stores of every second step of RST are left out, which only makes the counted
     // waits stricter than needed
-    constexpr int kStores = LAST ? (RST ? SR + 2 : RES ? 2 * SR : SR) : 0;
+    // ITERS == 0 (residual and restriction alone) stores no smoothed plane
+    constexpr int kStores = LAST ? (NP > 0 ? SR : 0) + (RST ? 2 : RES ? SR : 0) : 0;
     constexpr int kLoads = MAP ? 3 * SR : 2 * SR;                     // per step
     constexpr int kYounger = kStores + (PD - 1) * (kLoads + kStores); // see wait_slot
     static_assert(kYounger < 64, "too many vector-memory operations in flight for a counted wait");
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
         // (two scalar adds each) instead of a 64-bit multiply per array and step.
         // The descriptors themselves are the running state: base address in words 0 and 1.
         desc_t d_in = plane_desc(inb + slab * (i0 + PD), in_bytes), d_f = plane_desc(f + slab * (i0 + PD), plane_bytes);
-        desc_t d_out = plane_desc(out + slab * (i0 - NP), plane_bytes);
+        desc_t d_out = plane_desc(NP > 0 ? out + slab * (i0 - NP) : (R *)f, plane_bytes);
         desc_t d_res = plane_desc(RES ? res + slab * (i0 - DR) : out, plane_bytes);
         // coarse plane written at the group's first step: fine plane i0 - 2 - DR is its centre
         desc_t d_rc = plane_desc(RST ? rcb + cf.slab * ((i0 - 2 - DR) / 2) : (R *)out, rcplane_bytes);
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                             hand[par][w][0][c][j][lane] = C[c][PH(NP)][j];
                             hand[par][w][1][c][j][lane] = F[c][PH(NP)][j];
                         }
-                } else if (FAST || (zf >= 0 && zf <= zlast)) {
+                } else if (NP > 0 && (FAST || (zf >= 0 && zf <= zlast))) {
                     const desc_t ro = FAST ? d_out : plane_desc(out + slab * zf, plane_bytes);
 #pragma unroll
                     for (int r = 0; r < SR; ++r)
@@ -696,7 +697,9 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                 if (FAST && (FIRST || LAST)) {
                     if (MAP)
                         advance(d_k, (unsigned long long)slab);
-                    advance(d_in, slab_bytes), advance(d_f, slab_bytes), advance(d_out, slab_bytes);
+                    advance(d_in, slab_bytes), advance(d_f, slab_bytes);
+                    if (NP > 0)
+                        advance(d_out, slab_bytes);
                     if (RES)
                         advance(d_res, slab_bytes);
                     if (RST && ((u + 1 + DR) & 1) != 0)
@@ -916,8 +919,8 @@ mgrt_status smooth_sweep_residual_restrict(const mgrt_grid *fine, const mgrt_gri
     if (mgrt_status st = require_init()) return st;
     if (mgrt_status st = check_grid(fine, who)) return st;
     if (mgrt_status st = check_grid(coarse, who)) return st;
-    MGRT_REQUIRE(out && rc && f, "%s: null field", who);
-    MGRT_REQUIRE(out != in && out != f && rc != out && rc != in && rc != f, "%s: outputs must not alias another field", who);
+    MGRT_REQUIRE(rc && f, "%s: null field", who);
+    MGRT_REQUIRE((!out || (out != in && out != f && rc != out)) && rc != in && rc != f, "%s: outputs must not alias another field", who);
     MGRT_REQUIRE(fine->dim == coarse->dim, "%s: grids of different dimension", who);
     MGRT_REQUIRE(coarse->nx == (fine->nx + 1) / 2 && coarse->gny == (fine->gny + 1) / 2,
                  "%s: coarse grid %dx%d is not the half of %dx%d", who, coarse->nx, coarse->gny, fine->nx, fine->gny);
@@ -926,33 +929,51 @@ mgrt_status smooth_sweep_residual_restrict(const mgrt_grid *fine, const mgrt_gri
         return fail(MGRT_E_UNSUPPORTED, "%s: byte cell maps are not supported", who);
     if (neumann_extension(fine))
         return fail(MGRT_E_UNSUPPORTED, "%s: the first-order Neumann condition is in mgrt_smooth_pass only", who);
-    if (iters != 1 && iters != 2)
-        return fail(MGRT_E_UNSUPPORTED, "%s: iters must be 1 or 2, got %d", who, iters);
+    if (iters < 0 || iters > 2)
+        return fail(MGRT_E_UNSUPPORTED, "%s: iters must be 0, 1 or 2, got %d", who, iters);
+    MGRT_REQUIRE(iters > 0 ? out != nullptr : in != nullptr, "%s: null field", who);
     if (fine->nx % 2 == 0 || fine->ny % 2 == 0)
         return fail(MGRT_E_UNSUPPORTED, "%s: grids with odd extents only", who);
     if (fine->y0 != 0 || fine->ny != fine->gny || coarse->y0 != 0 || coarse->ny != coarse->gny)
         return fail(MGRT_E_UNSUPPORTED, "%s: whole grids only, not y-slabs", who);
-    if (fine->dim == 2)
+    if (fine->dim == 2) {
+        if (iters == 0)
+            return fail(MGRT_E_UNSUPPORTED, "%s: in 2D, iters must be 1 or 2", who);
         return smooth_sweep_2d(fine, coarse, out, rc, in, nullptr, f, omega, iters, (hipStream_t)s);
+    }
     MGRT_REQUIRE(coarse->nz == (fine->nz + 1) / 2, "%s: coarse grid has %d planes for %d", who, coarse->nz, fine->nz);
     if (!restrict_sweep_3d_supported(fine, sizeof(R), iters))
-        return fail(MGRT_E_UNSUPPORTED, "%s: in 3D, whole grids with odd extents and more than 300^2 columns, 4-byte "
-                                        "elements and iters == 2 only", who);
+        return fail(MGRT_E_UNSUPPORTED, "%s: in 3D, whole grids with odd extents; with iters == 2 more than 300^2 columns and "
+                                        "4-byte elements, with iters == 0 any element size; not iters == 1", who);
     MGRT_REQUIRE(r && r != out && r != rc && r != in && r != f, "%s: in 3D, r must be a work array of its own", who);
-    if constexpr (sizeof(R) == 4) {
-        // The sweep forms every coarse row except the one on each seam between two rows of tiles; it leaves
-        // the three fine residual rows around such a seam in r, and the restriction of those coarse rows
-        // alone follows.
-        constexpr int SR = 4, NW = 8, H = 5, OY = NW * SR - 2 * H;
-        const int parts = runtime().sweep_parts; // both, unless a timing harness asked for one alone
+    // The sweep forms every coarse row except the one on each seam between two rows of tiles; it leaves
+    // the three fine residual rows around such a seam in r, and the restriction of those coarse rows
+    // alone follows.
+    const int parts = runtime().sweep_parts; // both, unless a timing harness asked for one alone
+    hipStream_t hs = (hipStream_t)s;
+    int oy = 0;
+    mgrt_status st = MGRT_OK;
+    if (iters == 0) {
+        // no smoothing: the residual of `in` and its restriction in one march over in and f (one ring of
+        // halo, strips of two rows on the levels whose march is a latency chain)
+        // (8-byte elements: strips of four rows with two planes prefetched, for registers)
+        const bool small = latency_bound_level(*fine);
+        oy = (small ? 16 : 32) - 2;
         if (parts & 1)
-            if (mgrt_status st = launch<R, 2, SR, NW, 4, true, false, 1, false, true>(fine, out, in, f, omega, zcount,
-                                                                                     (hipStream_t)s, r, coarse, nullptr, rc))
-                return st;
-        const int nseams = (fine->ny + OY - 1) / OY - 1;
-        return parts & 2 ? restrict_rows(fine, coarse, rc, r, OY / 2, OY / 2, nseams, (hipStream_t)s) : MGRT_OK;
+            st = small ? launch<R, 0, 2, 8, 4, true, false, 1, false, true>(fine, nullptr, in, f, omega, zcount, hs, r, coarse, nullptr, rc)
+                       : launch<R, 0, 4, 8, sizeof(R) == 4 ? 4 : 2, true, false, 1, false, true>(fine, nullptr, in, f, omega, zcount, hs, r, coarse, nullptr, rc);
+    } else if constexpr (sizeof(R) == 4) {
+        constexpr int SR = 4, NW = 8, H = 5;
+        oy = NW * SR - 2 * H;
+        if (parts & 1)
+            st = launch<R, 2, SR, NW, 4, true, false, 1, false, true>(fine, out, in, f, omega, zcount, hs, r, coarse, nullptr, rc);
+    } else {
+        return fail(MGRT_E_UNSUPPORTED, "%s: no 3D kernel for this element size", who);
     }
-    return fail(MGRT_E_UNSUPPORTED, "%s: no 3D kernel for this element size", who);
+    if (st != MGRT_OK)
+        return st;
+    const int nseams = (fine->ny + oy - 1) / oy - 1;
+    return parts & 2 ? restrict_rows(fine, coarse, rc, r, oy / 2, oy / 2, nseams, hs) : MGRT_OK;
 }
 
 } // namespace
@@ -973,10 +994,10 @@ extern "C" mgrt_status mgrt_smooth_sweep_residual_restrict_f64(const mgrt_grid *
 
 extern "C" int mgrt_smooth_sweep_residual_restrict_supported(const mgrt_grid *fine, int elem_size, int iters)
 {
-    if (!fine || fine->cells || (iters != 1 && iters != 2) || (elem_size != 4 && elem_size != 8) || neumann_extension(fine) ||
+    if (!fine || fine->cells || iters < 0 || iters > 2 || (elem_size != 4 && elem_size != 8) || neumann_extension(fine) ||
         fine->nx % 2 == 0 || fine->gny % 2 == 0 || fine->y0 != 0 || fine->ny != fine->gny)
         return 0;
-    return fine->dim == 2 || restrict_sweep_3d_supported(fine, (size_t)elem_size, iters);
+    return fine->dim == 2 ? iters > 0 : restrict_sweep_3d_supported(fine, (size_t)elem_size, iters);
 }
 
 extern "C" int mgrt_correct_smooth_sweep_supported(const mgrt_grid *fine, int elem_size, int iters)

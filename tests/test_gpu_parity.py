@@ -807,3 +807,45 @@ def test_plan_with_restriction_in_sweep_equals_separate_restriction(dev):
         plan.close()
         out.append(u.cpu().numpy())
     assert bits_equal(out[0], out[1])
+
+
+# (nz, ny, nx): planes below and above the 300^2-column limit (strips of two and of four rows), tile row
+# seams (every 14 or 30 rows) that fall on the last grid row or leave a last tile row of one grid row, a
+# narrow last tile column, the smallest plane count
+RESRST_SHAPES = [(9, 29, 61), (5, 31, 63), (17, 45, 121), (7, 65, 65), (5, 331, 305), (9, 361, 303)]
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", RESRST_SHAPES, ids=lambda s: "x".join(map(str, s[::-1])))
+def test_3d_residual_restriction_march_matches_oracle(dev, mgo, shape, dt):
+    """mgrt_smooth_sweep_residual_restrict with iters == 0: compute_residuals + restrict
+    (multigridsolver3D.cpp:61,64; residual_kernel mg_1.cl:111-133, reduction_kernel :146-190) in one march
+    that never writes the fine residual (the rows next to tile seams aside), bit for bit the oracle's two
+    kernels, Dirichlet and mixed faces."""
+    import torch
+    from multigrid_amd import _lib as L
+    tdt = torch.float32 if dt is np.float32 else torch.float64
+    rng = np.random.default_rng(99 + shape[1] + shape[2])
+    cs = tuple((s + 1) // 2 for s in shape)
+    for faces in ((2,) * 6, (2, 3, 3, 2, 2, 3), (3, 2, 2, 3, 3, 2)):
+        cell = mgo.box_cells(shape, faces)
+        g, gc = L.grid(shape, faces=faces), L.grid(cs, faces=faces)
+        assert L.restrict_sweep_supported(g, tdt, 0)
+        u = rng.standard_normal(shape).astype(dt)
+        f = rng.standard_normal(shape).astype(dt)
+        r = np.zeros_like(u)  # cells the reference leaves unwritten count as 0
+        mgo.residual(cell, r, u, f)
+        want_c = np.empty(cs, dt)
+        mgo.restrict(cell, want_c, r)
+        du, df = to_dev(u, dev), to_dev(f, dev)
+        got_c = torch.full(cs, 4.0, dtype=tdt, device=dev)
+        work = torch.full(shape, 9.0, dtype=tdt, device=dev)
+        L.smooth_sweep_residual_restrict(g, gc, None, got_c, du, df, 1.0, 0, r=work)
+        torch.cuda.synchronize()
+        assert bits_equal(du.cpu().numpy(), u)  # the input is not touched
+        gc_host = got_c.cpu().numpy()
+        if not bits_equal(gc_host, want_c):
+            bits = np.uint32 if dt is np.float32 else np.uint64
+            bad = np.argwhere(gc_host.view(bits) != want_c.view(bits))
+            raise AssertionError((shape, faces, "rc", len(bad), bad[:8].tolist(), sorted(set(bad[:, 1].tolist()))[:12],
+                                  sorted(set(bad[:, 2].tolist()))[:12], sorted(set(bad[:, 0].tolist()))[:12]))

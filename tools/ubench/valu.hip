@@ -13,6 +13,9 @@ template <int OP> __global__ void k(float *out, int iters, float seed)
     for (int i = 0; i < 16; ++i) a[i] = seed + threadIdx.x + i;
     double d0 = seed, d1 = seed + 1;
     const unsigned long long mask = 0x5555555555555555ull ^ (unsigned long long)iters;
+    const unsigned vmask = (threadIdx.x & 1) ? 0xffffffffu : 0u, vsel = (threadIdx.x & 1) ? 0x03020100u : 0x07060504u;
+    const float vsixm = -6.0f;
+    asm volatile("s_mov_b64 vcc, %0" : : "s"(mask) : "vcc");
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -28,6 +31,36 @@ template <int OP> __global__ void k(float *out, int iters, float seed)
             if (OP == 7) asm volatile("v_add_f32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(a[(i + 1) & 15]));
             if (OP == 8) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(seed));
             if (OP == 9) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(seed));
+            // selects that take their condition from a vector register (all ones / zero per lane) instead of a scalar pair
+            if (OP == 12) asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(vmask), "v"(a[(i + 5) & 15]), "v"(a[(i + 9) & 15]));
+            if (OP == 13) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 9) & 15]), "v"(vsel));
+            if (OP == 14) asm volatile("v_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 9) & 15]) : );
+            if (OP == 15) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 9) & 15]), "v"(a[(i + 3) & 15]));
+            if (OP == 16) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d1) : "v"(d0));
+            if (OP == 17) asm volatile("v_ldexp_f64 %0, %0, -3" : "+v"(d1));
+            if (OP == 18) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*(double *)&a[i & 14]) : "v"(d0));
+            if (OP == 19) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*(double *)&a[i & 14]) : "v"(d0));
+            // the mix of an update: adds and selects alternating
+            if (OP == 20) {
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(seed));
+                asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a[(i + 8) & 15]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 9) & 15]), "s"(mask));
+            }
+            if (OP == 21) {
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(seed));
+                asm volatile("v_bfi_b32 %0, %1, %2, %3" : "=v"(a[(i + 8) & 15]) : "v"(vmask), "v"(a[(i + 5) & 15]), "v"(a[(i + 9) & 15]));
+            }
+            // x/6 three ways: through double as the reference's expression reads, and the two-step correction in single
+            if (OP == 22) {
+                asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d1) : "v"(a[i]));
+                asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d1) : "v"(d0));
+                asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a[i]) : "v"(d1));
+            }
+            if (OP == 23) {
+                float q, r;
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q) : "v"(a[i]), "v"(seed));
+                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(vsixm), "v"(q), "v"(a[i]));
+                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(r), "v"(seed), "v"(q));
+            }
         }
     }
     float s = (float)d1;
@@ -39,7 +72,7 @@ template <int OP> __global__ void k(float *out, int iters, float seed)
 template <int OP> void run(const char *name, float *out)
 {
     const int iters = 4000;
-    printf("%-16s", name);
+    printf("%-20s", name);
     for (int waves : {4, 8, 16}) { // per CU: 1, 2, 4 per SIMD
         hipEvent_t e0, e1;
         hipEventCreate(&e0), hipEventCreate(&e1);
@@ -72,6 +105,18 @@ int main()
     run<4>("v_cvt_f64_f32", out);
     run<5>("v_mul_f64", out);
     run<6>("v_cvt_f32_f64", out);
-    printf("(time per instruction and SIMD; at 2.4 GHz one cycle is 0.417 ns)\n");
+    run<12>("v_bfi_b32", out);
+    run<13>("v_perm_b32", out);
+    run<14>("v_cndmask vcc", out);
+    run<15>("v_fma_f32 4-reg", out);
+    run<16>("v_fma_f64", out);
+    run<17>("v_ldexp_f64", out);
+    run<18>("v_pk_fma_f32", out);
+    run<19>("v_pk_mul_f32", out);
+    run<20>("add+cndmask (2)", out);
+    run<21>("add+bfi (2)", out);
+    run<22>("x/6 via f64 (3)", out);
+    run<23>("x/6 mul,fma,fma (3)", out);
+    printf("(time per loop slot and SIMD: the rows marked (2) and (3) issue that many instructions per slot; at 2.4 GHz one cycle is 0.417 ns)\n");
     return 0;
 }
