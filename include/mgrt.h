@@ -146,6 +146,8 @@ int mgrt_sweep_parts(int mask);
        (multigridsolver2D.cpp:51,62,71, multigridsolver3D.cpp:50,61,64) in one pass over the       \
        fields.  Whole analytic-box grids with odd extents; in 3D only where                        \
        mgrt_smooth_sweep_residual_restrict_supported says so (MGRT_E_UNSUPPORTED otherwise).       \
+       iters == 0 (3D, either element size): no smoothing, out is not used (NULL), in must be      \
+       given: rc = Restrict(residual of `in`), compute_residuals and restrict alone in one march.  \
        r: 2D: not used, may be NULL.  3D: a work array of the fine grid's size; the sweep forms    \
        every coarse row but those on the seams between its rows of tiles, leaves the fine          \
        residual rows around those seams in r (the rest of r is not written) and a restriction of   \
@@ -157,8 +159,8 @@ int mgrt_sweep_parts(int mask);
     /* out = S^iters(u + 4*P(e)): the results of mgrt_correct followed by mgrt_smooth_sweep, the   \
        corrected field never written.  Replaces correct_residual followed by the post-smoothing    \
        smoother_iterate (multigridsolver2D.cpp:77,92, multigridsolver3D.cpp:70,77).  Analytic-box  \
-       grids with odd extents; in 3D only 4-byte elements, iters == 2, an even y0 and more than    \
-       300*300 columns (MGRT_E_UNSUPPORTED otherwise: call the two kernels).  out must not alias   \
+       grids with odd extents; in 3D only 4-byte elements, iters == 2, an even y0 and at least    \
+       100*100 columns (MGRT_E_UNSUPPORTED otherwise: call the two kernels).  out must not alias   \
        an input. */                                                                                \
     mgrt_status mgrt_correct_smooth_sweep##S(const mgrt_grid *fine, const mgrt_grid *coarse,       \
                                              R *out, const R *u, const R *e, const R *f, R omega,  \

@@ -102,8 +102,11 @@ inline bool plane_offsets_fit(const mgrt_grid *g, size_t elem)
 // separate correction.
 inline bool correct_sweep_3d_supported(const mgrt_grid *g, size_t elem, int iters)
 {
+    // from 100^2 columns up: below that the coarse loads lengthen the march by more than the correction's own
+    // launch costs (65^3: 42 us against 35 + 6)
     return g->dim == 3 && elem == 4 && iters == 2 && !g->cells && g->y0 % 2 == 0 && g->nx % 2 == 1 && g->gny % 2 == 1 &&
-           g->nz % 2 == 1 && g->nz >= 5 && !latency_bound_level(*g) && plane_offsets_fit(g, elem) && !neumann_extension(g);
+           g->nz % 2 == 1 && g->nz >= 5 && (long long)g->nx * g->ny >= 100LL * 100LL && plane_offsets_fit(g, elem) &&
+           !neumann_extension(g);
 }
 
 // Whether mgrt_smooth_sweep_residual_restrict has a 3D kernel for this level (the restriction carried in

@@ -105,7 +105,7 @@ template <class R> __device__ __forceinline__ R dot4(R a0, R a1, R a2, R a3, R b
 // bytes of a plane are prefetched beside its values (SR more loads per lane and step), packed two bits
 // a row into one register per plane in flight, and looked up where the box variant uses per-lane
 // constants; nothing else changes, so any domain a BorderHandler can describe takes the fused sweep.
-template <class R, int ITERS, int SR, int NW, int PD, bool OMEGA1, bool RES, bool COR = false, int STAGES = 1,
+template <class R, int ITERS, int SR, int NW, int PD, bool OMEGA1, bool RES, bool COR_ = false, int STAGES = 1,
           bool MAP = false, bool RST = false>
 __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid g, const R *__restrict__ in,
                                                               R *__restrict__ out, const R *__restrict__ f,
@@ -113,10 +113,10 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                                                               CoarseField cf)
 {
     static_assert(SR % 2 == 0, "rows are handled in pairs");
-    static_assert(!COR || (PD == 2 && !RES), "the corrected input is built for a prefetch depth of two planes");
-    static_assert(STAGES == 1 || (STAGES == 2 && !RES && !COR), "stages hand on whole smoothed planes only");
-    static_assert(!MAP || (STAGES == 1 && !RES && !COR && SR <= 16), "the byte-map variant is the plain sweep");
-    static_assert(!RST || (RES && !COR && STAGES == 1 && !MAP), "the restriction rides on the residual pass");
+    static_assert(!COR_ || (PD == 2 && !RES), "the corrected input is built for a prefetch depth of two planes");
+    static_assert(STAGES == 1 || (STAGES == 2 && !RES), "stages hand on whole smoothed planes only");
+    static_assert(!MAP || (STAGES == 1 && !RES && !COR_ && SR <= 16), "the byte-map variant is the plain sweep");
+    static_assert(!RST || (RES && !COR_ && STAGES == 1 && !MAP), "the restriction rides on the residual pass");
     constexpr int NP = 2 * ITERS, J = SR / 2;    // colour passes per stage
     constexpr int H = NP * STAGES + (RES ? 1 : 0); // halo rings consumed by all stages together
     constexpr int HX = H + (RST ? 1 : 0);        // in x the restriction takes one more
@@ -249,6 +249,7 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     auto march = [&](auto stage_tag) {
     constexpr int STG = decltype(stage_tag)::value;
     constexpr bool FIRST = STG == 0, LAST = STG == STAGES - 1; // FIRST loads from memory, LAST stores to it
+    constexpr bool COR = COR_ && FIRST;                        // the correction is applied where planes come in from memory
     constexpr int lag = STG * LAG;
     constexpr int WB = STG * NW; // this stage's wavefronts in bnd
     // per step; the coarse stores of every second step of RST are left out, which only makes the counted
@@ -799,6 +800,14 @@ template <> struct Cfg<double> {
     static constexpr int SR2 = 4, NW2 = 8, PF2 = 2; // 238-246 registers: one block of 8 waves per CU
 };
 
+// Whether the two-stage sweep of a latency-bound level takes six strips a stage (tiles of 64 x 12 with
+// 56 x 4 points of their own) rather than eight: when that still leaves every tile a CU to itself.
+bool two_stage_six_strips(const mgrt_grid &g)
+{
+    const long long tiles = (long long)((g.nx + 55) / 56) * ((g.ny + 3) / 4);
+    return tiles <= runtime().num_cu;
+}
+
 // res == nullptr: the sweep alone; otherwise the sweep with the residual pass.
 template <class R>
 mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, int iters, int zcount,
@@ -856,12 +865,18 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
     if (iters == 1)
         return small ? launch<R, 1, 2, 8, 4>(g, out, in, f, omega, zcount, hs)
                      : launch<R, 1, C::SR1, C::NW1, C::PF1>(g, out, in, f, omega, zcount, hs);
-    // Latency-bound levels: strips of two rows.  From about 100^2 columns up as two stages of one
-    // iteration each (16 wavefronts a block; measured 105 vs 114 us at 257^3, 54 vs 59 at 129^3), below
-    // that as one stage (20 vs 23 us at 33^3: few blocks, and the second stage only adds its lag).
+    // Latency-bound levels: strips of two rows, as two stages of one iteration each: a step of the march
+    // then costs what one wavefront issues in it, and a wavefront issues half as much (105 vs 119 us at
+    // 257^3).  Where tiles of six strips a stage still give every tile a CU of its own, those are taken:
+    // three wavefronts a SIMD instead of four (129^3: 49 vs 55 us, 65^3: 29 vs 35 and 37 for one stage,
+    // 33^3: 20 vs 22 and 23).
     if constexpr (sizeof(R) == 4) { // 16 wavefronts a block leave 128 registers a lane: tight for 8-byte elements
-        if (small && (long long)g->nx * g->ny >= 100LL * 100LL)
-            return launch<R, 1, 2, 8, 4, false, false, 2>(g, out, in, f, omega, zcount, hs);
+        if (small) {
+            if (!two_stage_six_strips(*g))
+                return launch<R, 1, 2, 8, 4, false, false, 2>(g, out, in, f, omega, zcount, hs);
+            return (long long)g->nx * g->ny >= 100LL * 100LL ? launch<R, 1, 2, 6, 2, false, false, 2>(g, out, in, f, omega, zcount, hs)
+                                                             : launch<R, 1, 2, 6, 4, false, false, 2>(g, out, in, f, omega, zcount, hs);
+        }
     }
     return small ? launch<R, 2, 2, sizeof(R) == 4 ? 8 : 12, 3>(g, out, in, f, omega, zcount, hs)
                  : launch<R, 2, C::SR2, C::NW2, C::PF2>(g, out, in, f, omega, zcount, hs);
@@ -898,11 +913,17 @@ mgrt_status correct_smooth_sweep(const mgrt_grid *fine, const mgrt_grid *coarse,
                      coarse->nz, fine->nz);
         if (!correct_sweep_3d_supported(fine, sizeof(R), iters))
             return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: in 3D, 4-byte elements, iters == 2, odd extents, an "
-                                            "even slab offset and more than 300^2 columns only");
+                                            "even slab offset and at least 100^2 columns only");
         if constexpr (sizeof(R) == 4) {
             using C = Cfg<R>;
-            return launch<R, 2, C::SR2, C::NW2, C::PF2, false, true>(fine, out, u, f, omega, zcount, (hipStream_t)s, nullptr,
-                                                                     coarse, e);
+            // the shapes of the plain sweep on each kind of level, two planes prefetched
+            if (!latency_bound_level(*fine))
+                return launch<R, 2, C::SR2, C::NW2, C::PF2, false, true>(fine, out, u, f, omega, zcount, (hipStream_t)s, nullptr,
+                                                                         coarse, e);
+            // latency-bound levels: two stages of one iteration each, the correction in the first
+            if (two_stage_six_strips(*fine))
+                return launch<R, 1, 2, 6, 2, false, true, 2>(fine, out, u, f, omega, zcount, (hipStream_t)s, nullptr, coarse, e);
+            return launch<R, 1, 2, 8, 2, false, true, 2>(fine, out, u, f, omega, zcount, (hipStream_t)s, nullptr, coarse, e);
         }
         return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: no 3D kernel for this element size");
     }

@@ -360,10 +360,12 @@ def test_fused_sweep_2d_with_residual_and_with_correction(dev, mgo, dt, shape):
                     assert bits_equal(outs[h + 1:-h - 1].cpu().numpy(), ref[y0:y1]), (shape, faces, iters, "corrected slab")
 
 
-@pytest.mark.parametrize("shape", [(9, 321, 305), (5, 331, 303), (33, 303, 513), (17, 611, 309)],
+@pytest.mark.parametrize("shape", [(9, 321, 305), (5, 331, 303), (33, 303, 513), (17, 611, 309),
+                                   (7, 129, 131), (5, 257, 259), (9, 121, 123)],
                          ids=lambda s: "x".join(map(str, s[::-1])))
 def test_fused_sweep_3d_with_correction(dev, mgo, shape):
-    """3D, wide planes: the sweep whose input is u + 4*P(e) against the correction kernel followed by
+    """3D, wide planes (strips of four rows) and planes of 100^2 to 300^2 columns (two stages of one iteration
+    each, the correction in the first): the sweep whose input is u + 4*P(e) against the correction kernel followed by
     the sweep (both checked against the oracle elsewhere) and, for the smallest case, against the
     oracle itself; whole grids, both z ranges, a y-slab at an even offset; and the cases the kernel
     declines."""
