@@ -187,6 +187,9 @@ int mgrt_sweep_parts(int mask);
     mgrt_status mgrt_zero_outside##S(const mgrt_grid *g, R *u, mgrt_stream s);                     \
     /* out = a - b over the grid.  Replaces Diff (common_kernels.cl:56-62, auxiliary.h:96-109). */ \
     mgrt_status mgrt_diff##S(const mgrt_grid *g, R *out, const R *a, const R *b, mgrt_stream s);   \
+    /* out = in * m over the grid, m a float whatever the element type; out may alias in.          \
+       Replaces Mult (common_kernels.cl:65-72), which the reference builds and never launches. */  \
+    mgrt_status mgrt_scale##S(const mgrt_grid *g, R *out, const R *in, float m, mgrt_stream s);    \
     /* Exact norms over rows ylo..yhi: sum of squares / max |x| accumulated in double into a      \
        device scalar, deterministic (fixed two-stage reduction, no atomics).  These are the       \
        engine's norms; the reference's lossy tree is below. */                                    \
@@ -271,7 +274,9 @@ mgrt_status mgrt_plan_fmg(mgrt_plan *plan, void *u_out, const void *f, double om
  * of one: the cut is along y only, so every z column, and the z recurrence of a colour pass with it,
  * stays on one rank.  Rank r owns rows [B_r, B_r+1) of level 0, B_r a multiple of 2^(levels cut), and
  * stores four halo rows of each neighbour; levels of at most `crossover` points are gathered and
- * solved whole on every rank.  3D grids, analytic box.
+ * solved whole on every rank.  3D grids with analytic-box domains only: there is no way to hand a slab
+ * plan a byte cell map or a 2D grid (mgrt_slab_plan_create returns MGRT_E_UNSUPPORTED for dim != 3 through
+ * its extents check); MappedBorderHandler domains and multigrid2D run on one GPU.
  *
  * How halos travel is the transport's business:
  *   MGRT_TRANSPORT_RCCL      ncclSend/ncclRecv with the two neighbours, ncclAllGather, ncclAllReduce on
@@ -329,11 +334,14 @@ int mgrt_slab_plan_uses_graph(const mgrt_slab_plan *plan);
 mgrt_status mgrt_slab_plan_rows(const mgrt_slab_plan *plan, int *lo, int *hi, int *own_lo, int *own_hi);
 /* `ncycles` times iterate(u, f, omega, a1, a2, v) on this rank's rows: u (in/out) and f are dense
  * device arrays of nz x (hi - lo) x nx elements, halo rows included; those of f must be filled, those
- * of u are exchanged here.  res_hist as in mgrt_plan_vcycle, norms over the whole grid. */
+ * of u are exchanged here before they are read.  On return only the owned rows [own_lo, own_hi) of u are
+ * defined: the halo rows hold whatever the last sweep left there, not the neighbours' values.
+ * res_hist as in mgrt_plan_vcycle, norms over the whole grid. */
 mgrt_status mgrt_slab_plan_vcycle(mgrt_slab_plan *plan, void *u, const void *f, double omega, int a1, int a2, int v,
                                   int ncycles, double *res_hist);
-/* fmg(f, omega, a1, a2, v, iters) of multigridsolver3D.cpp:82-109 on this rank's rows: u_out is written (halo
- * rows included), f as for mgrt_slab_plan_vcycle.  Coarse levels run the default of 3 cycles as in the reference. */
+/* fmg(f, omega, a1, a2, v, iters) of multigridsolver3D.cpp:82-109 on this rank's rows: u_out is written (its
+ * owned rows are the result; the halo rows are overwritten with values that are not the neighbours'), f as
+ * for mgrt_slab_plan_vcycle.  Coarse levels run the default of 3 cycles as in the reference. */
 mgrt_status mgrt_slab_plan_fmg(mgrt_slab_plan *plan, void *u_out, const void *f, double omega, int a1, int a2, int v,
                                int iters);
 

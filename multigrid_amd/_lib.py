@@ -64,7 +64,7 @@ class SlabDesc(C.Structure):
 
 # every symbol include/mgrt.h declares; checked by the CPU test-suite against the header
 _KERNELS = ["smooth_pass", "smooth", "smooth_sweep", "smooth_sweep_residual", "smooth_sweep_residual_restrict", "correct_smooth_sweep", "residual", "restrict", "correct", "prolong", "zero_outside",
-            "diff", "sumsq", "maxabs", "l2norm_reftree", "linfnorm_reftree", "sum_reftree"]
+            "diff", "scale", "sumsq", "maxabs", "l2norm_reftree", "linfnorm_reftree", "sum_reftree"]
 _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "upload", "download",
             "stream_create", "stream_destroy", "sync", "zero", "box_cells_host",
             "plan_create", "plan_destroy", "plan_levels", "plan_level_dims", "plan_set_cells",
@@ -139,6 +139,7 @@ def load():
             "prolong": [G, G, p, p, i, i, p],
             "zero_outside": [G, p, p],
             "diff": [G, p, p, p, p],
+            "scale": [G, p, p, C.c_float, p],
             "sumsq": [G, p, p, i, i, p],
             "maxabs": [G, p, p, i, i, p],
             "l2norm_reftree": [p, ll, C.POINTER(r), p],
@@ -286,6 +287,10 @@ def zero_outside(g, u, stream=None):
 
 def diff(g, out, a, b, stream=None):
     check(_fn("diff", a)(C.byref(g), _p(out), _p(a), _p(b), _stream(stream)))
+
+
+def scale(g, out, x, m, stream=None):
+    check(_fn("scale", x)(C.byref(g), _p(out), _p(x), m, _stream(stream)))
 
 
 def sumsq(g, x, out, ylo=0, yhi=None, stream=None):

@@ -643,6 +643,17 @@ template <class R> __global__ __launch_bounds__(256) void k_diff(mgrt_grid g, R 
     out[i] = a[i] - b[i];
 }
 
+// Mult, common_kernels.cl:65-72: the factor is a float whatever `real` is
+template <class R> __global__ __launch_bounds__(256) void k_scale(mgrt_grid g, R *out, const R *in, float m)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)g.nx * g.ny)
+        return;
+    const int y = (int)(idx / g.nx), x = (int)(idx % g.nx);
+    const long long i = x + (long long)g.pitch * y + g.slab * blockIdx.y;
+    out[i] = in[i] * m;
+}
+
 // exact sum of squares / max |x|, double accumulation, one partial per block
 template <class R, bool MAX>
 __global__ __launch_bounds__(256) void k_norm_partials(mgrt_grid g, const R *__restrict__ x, double *partials,
@@ -950,6 +961,17 @@ template <class R> mgrt_status diff(const mgrt_grid *g, R *out, const R *a, cons
     return MGRT_OK;
 }
 
+template <class R> mgrt_status scale(const mgrt_grid *g, R *out, const R *in, float m, mgrt_stream s)
+{
+    if (mgrt_status st = require_init()) return st;
+    if (mgrt_status st = check_grid(g, "mgrt_scale")) return st;
+    MGRT_REQUIRE(out && in, "mgrt_scale: null field");
+    dim3 grid(blocks_for((long long)g->nx * g->ny, 256), g->nz);
+    k_scale<R><<<grid, 256, 0, (hipStream_t)s>>>(*g, out, in, m);
+    MGRT_HIP(hipGetLastError());
+    return MGRT_OK;
+}
+
 template <class R, bool MAX>
 mgrt_status norm(const mgrt_grid *g, const R *x, double *out, int ylo, int yhi, mgrt_stream s)
 {
@@ -1090,6 +1112,8 @@ template <class R, int MODE> mgrt_status reftree(const R *x, long long n, R *res
     { return zero_outside<R>(g, u, s); }                                                                       \
     extern "C" mgrt_status mgrt_diff##S(const mgrt_grid *g, R *out, const R *a, const R *b, mgrt_stream s)     \
     { return diff<R>(g, out, a, b, s); }                                                                       \
+    extern "C" mgrt_status mgrt_scale##S(const mgrt_grid *g, R *out, const R *in, float m, mgrt_stream s)      \
+    { return scale<R>(g, out, in, m, s); }                                                                     \
     extern "C" mgrt_status mgrt_sumsq##S(const mgrt_grid *g, const R *x, double *out, int ylo, int yhi,        \
                                          mgrt_stream s)                                                        \
     { return norm<R, false>(g, x, out, ylo, yhi, s); }                                                         \

@@ -67,6 +67,7 @@ enum { MGO_INNER = 0, MGO_OUTER = 1, MGO_DIRICHLET = 2, MGO_NEUMANN = 3 };
     R MGO_NAME(l2norm_tree##S)(const R *x, long n);                                                \
     R MGO_NAME(linfnorm_tree##S)(const R *x, long n);                                              \
     void MGO_NAME(diff##S)(R *out, const R *a, const R *b, long n);                                \
+    void MGO_NAME(scale##S)(R *out, const R *in, float m, long n);                                 \
     /* host drivers restated from multigridsolver3D.cpp:41-132 (2D: multigridsolver2D.cpp:42-147). \
        zfull != 0 launches the 3D smoother over every z plane instead of ceil(nz/2).              \
        u is updated in place (the reference rebinds the caller's handle to the new data). */      \

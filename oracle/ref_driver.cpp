@@ -97,6 +97,7 @@ DECL_MG(r3d_, d4, double, i4)
     void P##LInfNorm(R *, R *, int, int);                                                          \
     void P##SumAll(R *, R *, int, int);                                                            \
     void P##Diff(R *, R *, R *);                                                                   \
+    void P##Mult(R *, R *, float);                                                                 \
     }
 DECL_COMMON(rcf_, float)
 DECL_COMMON(rcd_, double)
@@ -202,6 +203,10 @@ DECL_COMMON(rcd_, double)
     extern "C" void mgr_diff##S(R *out, const R *a, const R *b, long n)                            \
     { /* auxiliary.h:96-109 */                                                                     \
         ndrange((size_t)n, 1, 1, [&] { PC##Diff(out, (R *)a, (R *)b); });                          \
+    }                                                                                              \
+    extern "C" void mgr_scale##S(R *out, const R *in, float m, long n)                             \
+    { /* Mult has no launch site in the reference: one work-item per element, as for Diff */       \
+        ndrange((size_t)n, 1, 1, [&] { PC##Mult((R *)in, out, m); });                              \
     }
 
 WRAP(float, _f32, r2f_, r3f_, rcf_, f2, f4)

@@ -39,6 +39,7 @@ class Oracle:
             self._sig("l2norm_tree" + S, r, [p, l])
             self._sig("linfnorm_tree" + S, r, [p, l])
             self._sig("diff" + S, None, [p, p, p, l])
+            self._sig("scale" + S, None, [p, p, C.c_float, l])
             self._sig("smoother_iterate" + S, None, [i, p, p, r, i, i, i, i, i])
             self._sig("iterate" + S, None, [i, p, p, r, i, i, i, i, i, i, i])
             self._sig("mg" + S, None, [i, p, p, r, i, i, i, i, i, i, i, i])
@@ -109,6 +110,11 @@ class Oracle:
     def diff(self, a, b):
         out = np.empty_like(a)
         getattr(self, "_diff" + self._S(a))(_ptr(out), _ptr(a), _ptr(b), a.size)
+        return out
+
+    def scale(self, a, m):
+        out = np.empty_like(a)
+        getattr(self, "_scale" + self._S(a))(_ptr(out), _ptr(a), m, a.size)
         return out
 
     # ---- host drivers --------------------------------------------------------------------------

@@ -8,7 +8,10 @@ FACES: six cell classes x-lo,x-hi,y-lo,y-hi,z-lo,z-hi (2 Dirichlet, 3 Neumann), 
 BACKEND cpu: gloo, CPU tensors, oracle-backed kernels, the Python driver (multigrid_amd/dist.py).
 BACKEND gpu: the same driver with the HIP kernels, every rank on cuda:0, gloo with host staging.
 BACKEND native: mgrt_slab_plan of libmgrt.so (the C++ driver) on cuda:0 with callbacks over gloo.
-BACKEND native-fmg: the same plan's full multigrid (NCYCLES = its iters) against the oracle's fmg."""
+BACKEND native-fmg: the same plan's full multigrid (NCYCLES = its iters) against the oracle's fmg.
+BACKEND rccl, rccl-nograph: mgrt_slab_plan with the RCCL transport, every rank on the GPU of its LOCAL_RANK
+(needs as many GPUs as ranks); halos, gathers and norms travel over RCCL, the cycle replayed from a graph
+or launched directly."""
 import os
 import sys
 
@@ -59,6 +62,10 @@ def main():
         o.residual(cell, r, x, f)
         return o.l2norm_exact(r)
     fmg = backend == "native-fmg"
+    rccl = backend.startswith("rccl")
+    use_graph = backend != "rccl-nograph"
+    if rccl:
+        backend = "native"
     if fmg:
         backend = "native"
         ref = o.fmg(f, dt(omega), a1, a2, v, ncycles, zfull)
@@ -74,11 +81,19 @@ def main():
         kernels, device = OracleKernels(), None
     else:
         from multigrid_amd import _lib as kernels
-        torch.cuda.set_device(0)
-        kernels.init(0)
-        device = torch.device("cuda", 0)
+        local = int(os.environ.get("LOCAL_RANK", "0")) if rccl else 0
+        torch.cuda.set_device(local)
+        kernels.init(local)
+        device = torch.device("cuda", local)
     to = (lambda a: torch.from_numpy(a.copy())) if device is None else (lambda a: torch.from_numpy(a.copy()).to(device))
-    if backend == "native":
+    if rccl:
+        box = [kernels.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        cyc = kernels.SlabPlan(shape, tdt, transport="rccl", rank=rank, nranks=world, rccl_id=box[0], zfull=zfull,
+                               crossover=crossover, faces=faces, use_graph=use_graph)
+        ndist = cyc.distributed_levels
+        lo, hi, a, b = cyc.rows()
+    elif backend == "native":
         cyc = kernels.SlabPlan(shape, tdt, transport=kernels.GlooTransport(), zfull=zfull, crossover=crossover, faces=faces)
         ndist = cyc.distributed_levels
         lo, hi, a, b = cyc.rows()

@@ -111,6 +111,8 @@ def test_kernels_match_oracle(dev, mgo, dt, shape):
         d = torch.empty_like(du)
         L.diff(g, d, du, df)
         assert bits_equal(d.cpu().numpy(), mgo.diff(u, f)), (name, "diff")
+        L.scale(g, d, du, 0.3)
+        assert bits_equal(d.cpu().numpy(), mgo.scale(u, 0.3)), (name, "scale")
         # norms: the engine's exact ones and the reference's lossy tree
         out = torch.zeros(1, dtype=torch.float64, device=dev)
         L.sumsq(g, du, out)

@@ -8,6 +8,20 @@ from multigrid_amd import _lib
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("backend", ["rccl", "rccl-nograph"])
+@pytest.mark.parametrize("world", [2, 4])
+def test_slab_plan_over_rccl_between_gpus_matches_the_oracle(world, backend):
+    """mgrt_slab_plan with MGRT_TRANSPORT_RCCL on `world` GPUs, one process each: ncclSend/ncclRecv between
+    neighbours, all-gather of the coarse rows, all-reduce of the norms, the cycle captured into a graph per
+    rank (or launched directly).  Every rank's rows bit for bit the oracle's whole-grid cycle.  Needs that
+    many GPUs: skipped on a one-GPU box, and the first thing to look at on a node."""
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs, %d visible" % (world, torch.cuda.device_count()))
+    from test_dist import launch
+    launch(world, backend, (33, 129, 65), "f32", 1.0, 2, 2, 1, 2, True, 9 ** 3, timeout=600)
+    launch(world, backend, (17, 129, 33), "f64", 0.9, 2, 2, 1, 2, True, 9 ** 3, timeout=600)
+
+
 def test_rccl_operations_direct_and_from_a_graph():
     # send/receive with itself in one group, all-gather, all-reduce through the dlopen'ed symbols (id by
     # value, enum values as in rccl.h), then the same captured into a hipGraph and replayed twice on

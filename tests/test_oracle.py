@@ -126,6 +126,7 @@ def test_restatement_matches_reference_kernels(mgo, mgr, dt, shape):
         assert mgo.l2norm_tree(u) == mgr.l2norm_tree(u)
         assert mgo.linfnorm_tree(u) == mgr.linfnorm_tree(u)
         assert bits_equal(mgo.diff(u, f), mgr.diff(u, f))
+        assert bits_equal(mgo.scale(u, 0.3), mgr.scale(u, 0.3))
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 17, 289, 4913])
