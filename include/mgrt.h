@@ -147,7 +147,9 @@ int mgrt_sweep_parts(int mask);
        fields.  Whole analytic-box grids with odd extents; in 3D only where                        \
        mgrt_smooth_sweep_residual_restrict_supported says so (MGRT_E_UNSUPPORTED otherwise).       \
        iters == 0 (3D, either element size): no smoothing, out is not used (NULL), in must be      \
-       given: rc = Restrict(residual of `in`), compute_residuals and restrict alone in one march.  \
+       given: rc = Restrict(residual of `in`), compute_residuals and restrict alone, in whichever   \
+       form is fastest for the level (one march, one launch through LDS, or the two kernels with   \
+       the residual passing through r).                                                            \
        r: 2D: not used, may be NULL.  3D: a work array of the fine grid's size; the sweep forms    \
        every coarse row but those on the seams between its rows of tiles, leaves the fine          \
        residual rows around those seams in r (the rest of r is not written) and a restriction of   \

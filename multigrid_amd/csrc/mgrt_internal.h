@@ -127,6 +127,12 @@ mgrt_status restrict_rows(const mgrt_grid *fine, const mgrt_grid *coarse, float 
 mgrt_status restrict_rows(const mgrt_grid *fine, const mgrt_grid *coarse, double *rc, const double *rf, int j0, int jstep,
                           int nrows, hipStream_t hs);
 
+// rc = Restrict(f - A u) on a whole 3D analytic box, tile by tile with the fine residual in LDS only.
+mgrt_status residual_restrict_tiles(const mgrt_grid *fine, const mgrt_grid *coarse, float *rc, const float *u, const float *f,
+                                    hipStream_t hs);
+mgrt_status residual_restrict_tiles(const mgrt_grid *fine, const mgrt_grid *coarse, double *rc, const double *u, const double *f,
+                                    hipStream_t hs);
+
 // out = S^iters(in) on a 2D analytic-box grid, iters 1 or 2 (mgrt_smooth2d.hip); in may be null.
 // res (optional) receives the residual of out or, when cg is given without e, its restriction to
 // the coarse grid cg; e with its coarse grid cg (optional) makes the input in + 4*P(e).

@@ -33,6 +33,9 @@ constexpr int kWave = 64;
 template <class R>
 mgrt_status restrict_rows_impl(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, const R *rf, int j0, int jstep, int nrows,
                                hipStream_t hs);
+template <class R>
+mgrt_status residual_restrict_tiles_impl(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, const R *u, const R *f,
+                                         hipStream_t hs);
 
 } // namespace
 
@@ -46,6 +49,16 @@ mgrt_status restrict_rows(const mgrt_grid *fine, const mgrt_grid *coarse, double
                           int nrows, hipStream_t hs)
 {
     return restrict_rows_impl<double>(fine, coarse, rc, rf, j0, jstep, nrows, hs);
+}
+mgrt_status residual_restrict_tiles(const mgrt_grid *fine, const mgrt_grid *coarse, float *rc, const float *u, const float *f,
+                                    hipStream_t hs)
+{
+    return residual_restrict_tiles_impl<float>(fine, coarse, rc, u, f, hs);
+}
+mgrt_status residual_restrict_tiles(const mgrt_grid *fine, const mgrt_grid *coarse, double *rc, const double *u, const double *f,
+                                    hipStream_t hs)
+{
+    return residual_restrict_tiles_impl<double>(fine, coarse, rc, u, f, hs);
 }
 } // namespace mgrt
 
@@ -452,6 +465,79 @@ __global__ __launch_bounds__(256) void k_restrict(mgrt_grid fg, mgrt_grid cg, R 
         rc[d] = 1.0 / 16.0 * (c[-p - 1] + c[-p + 1] + c[p - 1] + c[p + 1]) +
                 1.0 / 8.0 * (c[-p] + c[1] + c[-1] + c[p]) + 1.0 / 4.0 * (c[0]);
     }
+}
+
+// ---- residual and restriction together, tile by tile -----------------------------------------------
+// rc = Restrict(f - A u) on a whole 3D analytic box (residual_kernel mg_1.cl:111-133 with the cells it
+// leaves unwritten counted as 0, then reduction_kernel :146-190) without the fine residual in memory: a
+// block forms the residuals under its tile of CX x CY x CZ coarse points, (2CX+1)(2CY+1)(2CZ+1) of them,
+// in LDS and sums them there, every expression as in k_residual3d_v and k_restrict.  For the levels on
+// which a march over z costs its step latency whatever it computes.
+template <class R>
+__global__ __launch_bounds__(1024) void k_residual_restrict3d(mgrt_grid fg, mgrt_grid cg, R *rc, const R *__restrict__ u,
+                                                              const R *__restrict__ f, int ntx, int nty)
+{
+    constexpr int CX = 31, CY = 4, CZ = 4, FX = 2 * CX + 1, FY = 2 * CY + 1, FZ = 2 * CZ + 1; // FX = 63: a row a wavefront
+    constexpr int ROWS = FY * FZ, NW = 16, NIT = (ROWS + NW - 1) / NW;
+    static_assert(FX <= 64, "a row of the tile is one wavefront wide");
+    __shared__ R rs[FZ * FY * 64];
+    const int b = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const int i0 = (b % ntx) * CX, j0 = (b / ntx % nty) * CY, k0 = (b / (ntx * nty)) * CZ;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long p = fg.pitch, s = fg.slab;
+    // residuals: row `row` of the tile (y fastest, then z) by wavefront row % 16, a lane a point.  All loads
+    // of all rows are issued before the first is used: addresses are clamped into the grid's interior, and
+    // what a clamped point computes is discarded.
+    const int x = 2 * i0 - 1 + lane, xc = x < 1 ? 1 : (x > fg.nx - 2 ? fg.nx - 2 : x);
+    R um[NIT], up[NIT], ym[NIT], yp[NIT], zm[NIT], zp[NIT], uc[NIT], fv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = wave + NW * it, y = 2 * j0 - 1 + row % FY, z = 2 * k0 - 1 + row / FY;
+        const int yc = y < 1 ? 1 : (y > fg.ny - 2 ? fg.ny - 2 : y), zc = z < 1 ? 1 : (z > fg.nz - 2 ? fg.nz - 2 : z);
+        const long long a = xc + p * yc + s * zc;
+        up[it] = u[a + 1], um[it] = u[a - 1], yp[it] = u[a + p], ym[it] = u[a - p], zp[it] = u[a + s], zm[it] = u[a - s];
+        // the point itself may lie on a face (a Dirichlet cell takes f - u there): its own address
+        const bool in = x >= 0 && x < fg.nx && y >= 0 && y < fg.ny && z >= 0 && z < fg.nz;
+        const long long own = in ? x + p * y + s * z : a;
+        uc[it] = u[own], fv[it] = f[own];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = wave + NW * it, y = 2 * j0 - 1 + row % FY, z = 2 * k0 - 1 + row / FY;
+        const bool in = x >= 0 && x < fg.nx && y >= 0 && y < fg.ny && z >= 0 && z < fg.nz;
+        const int cls = in ? cell_class<3, false>(fg, x, y, z) : (int)MGRT_CELL_OUTER;
+        const R vi = fv[it] - (up[it] + um[it] + yp[it] + ym[it] + zp[it] + zm[it] - 6 * uc[it]);
+        const R vd = fv[it] - uc[it];
+        if (row < ROWS)
+            rs[row * 64 + lane] = cls == MGRT_CELL_INNER ? vi : (cls == MGRT_CELL_DIRICHLET ? vd : (R)0);
+    }
+    __syncthreads();
+    const int ci = threadIdx.x % 32, cj = threadIdx.x / 32 % CY, ck = (int)threadIdx.x / (32 * CY);
+    const int i = i0 + ci, j = j0 + cj, k = k0 + ck;
+    if (ci >= CX || ck >= CZ || i >= cg.nx || j >= cg.ny || k >= cg.nz)
+        return;
+    const int xf = 2 * i, yf = 2 * j, zf = 2 * k;
+    constexpr int P = 64, S = 64 * FY;
+    const R *c = rs + (2 * ci + 1) + P * (2 * cj + 1) + S * (2 * ck + 1);
+    // as k_restrict: a centre on a face of the grid injects, and so does one whose forward 2x2x2 block
+    // holds a border cell
+    const bool on_face = xf == 0 || xf == fg.nx - 1 || yf == 0 || yf == fg.gny - 1 || zf == 0 || zf == fg.nz - 1;
+    bool border = on_face || is_border(cell_class<3, false>(fg, xf, yf, zf));
+    if (!border)
+        border = is_border(cell_class<3, false>(fg, xf + 1, yf, zf)) || is_border(cell_class<3, false>(fg, xf, yf + 1, zf)) ||
+                 is_border(cell_class<3, false>(fg, xf + 1, yf + 1, zf)) || is_border(cell_class<3, false>(fg, xf, yf, zf + 1)) ||
+                 is_border(cell_class<3, false>(fg, xf + 1, yf, zf + 1)) || is_border(cell_class<3, false>(fg, xf, yf + 1, zf + 1)) ||
+                 is_border(cell_class<3, false>(fg, xf + 1, yf + 1, zf + 1));
+    R val;
+    if (border)
+        val = c[0];
+    else
+        val = 1.0 / 64.0 * (c[S + P + 1] + c[S + P - 1] + c[S - P + 1] + c[S - P - 1] + c[-S + P + 1] + c[-S + P - 1] +
+                            c[-S - P + 1] + c[-S - P - 1]) +
+              1.0 / 32.0 * (c[P + 1] + c[P - 1] + c[-P + 1] + c[-P - 1] + c[-S + P] + c[-S - P] + c[-S + 1] + c[-S - 1] +
+                            c[S + P] + c[S - P] + c[S + 1] + c[S - 1]) +
+              1.0 / 16.0 * (c[P] + c[-P] + c[1] + c[-1] + c[S] + c[-S]) + 1.0 / 8.0 * (c[0]);
+    rc[i + (long long)cg.pitch * j + cg.slab * k] = val;
 }
 
 // ---- interpolation (mg_1.cl:200-267, mg_0.cl:167-222) -----------------------------------------
@@ -886,6 +972,20 @@ mgrt_status restrict_rows_impl(const mgrt_grid *fine, const mgrt_grid *coarse, R
     MGRT_REQUIRE(j0 >= 0 && jstep >= 1 && j0 + (long long)(nrows - 1) * jstep < coarse->ny, "restrict_rows: rows outside the grid");
     const unsigned nbxy = blocks_for((long long)coarse->nx * nrows, 256);
     k_restrict<R, 3, false><<<dim3(nbxy * (unsigned)coarse->nz), 256, 0, hs>>>(*fine, *coarse, rc, rf, j0, nrows, nbxy, jstep);
+    MGRT_HIP(hipGetLastError());
+    return MGRT_OK;
+}
+
+template <class R>
+mgrt_status residual_restrict_tiles_impl(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, const R *u, const R *f,
+                                         hipStream_t hs)
+{
+    MGRT_REQUIRE(fine->dim == 3 && !fine->cells && !neumann_extension(fine) && fine->y0 == 0 && fine->ny == fine->gny &&
+                     coarse->y0 == 0 && coarse->ny == coarse->gny,
+                 "residual_restrict_tiles: whole 3D analytic boxes only");
+    MGRT_REQUIRE(fine->nx >= 3 && fine->ny >= 3 && fine->nz >= 3, "residual_restrict_tiles: extents below 3");
+    const int ntx = (coarse->nx + 30) / 31, nty = (coarse->ny + 3) / 4, ntz = (coarse->nz + 3) / 4;
+    k_residual_restrict3d<R><<<dim3((unsigned)(ntx * nty * ntz)), 1024, 0, hs>>>(*fine, *coarse, rc, u, f, ntx, nty);
     MGRT_HIP(hipGetLastError());
     return MGRT_OK;
 }

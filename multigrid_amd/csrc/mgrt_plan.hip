@@ -202,11 +202,10 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
     const bool restrict_in_sweep =
         res_in_sweep && (L.g.dim == 2 || (!p->desc.separate_restrict &&
                                           mgrt_smooth_sweep_residual_restrict_supported(&L.g, (int)sizeof(R), n1 < a1 ? 2 : 1)));
-    // Where no sweep carries them, residual and restriction run as one march of their own on the
-    // bandwidth-bound 3D levels (on the others a march costs its step latency whatever it computes: 100 us
-    // against 54 us for the two kernels at 257^3).
+    // Where no sweep carries them, residual and restriction run as one launch (3D boxes): a march of its
+    // own on the bandwidth-bound levels, tile by tile through LDS on the others.
     const bool march_residual_restrict =
-        !p->desc.separate_restrict && !p->desc.no_fuse && recurses(L.g) && L.g.dim == 3 && !latency_bound_level(L.g) &&
+        !p->desc.separate_restrict && !p->desc.no_fuse && recurses(L.g) && L.g.dim == 3 &&
         mgrt_smooth_sweep_residual_restrict_supported(&L.g, (int)sizeof(R), 0);
     if (a1 > 0) {
         R *res = restrict_in_sweep ? (R *)p->lv[l + 1].rhs : res_in_sweep ? (R *)L.r : nullptr;

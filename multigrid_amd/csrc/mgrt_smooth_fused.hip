@@ -930,6 +930,16 @@ mgrt_status correct_smooth_sweep(const mgrt_grid *fine, const mgrt_grid *coarse,
     return smooth_sweep_2d(fine, coarse, out, nullptr, u, e, f, omega, iters, (hipStream_t)s);
 }
 
+template <class R> struct Step;
+template <> struct Step<float> {
+    static constexpr auto residual = mgrt_residual_f32;
+    static constexpr auto restrict_ = mgrt_restrict_f32;
+};
+template <> struct Step<double> {
+    static constexpr auto residual = mgrt_residual_f64;
+    static constexpr auto restrict_ = mgrt_restrict_f64;
+};
+
 // out = S^iters(in) and rc = Restrict(f - A out): the pre-smoother with everything the coarse level
 // needs from this one.
 template <class R>
@@ -975,14 +985,24 @@ mgrt_status smooth_sweep_residual_restrict(const mgrt_grid *fine, const mgrt_gri
     int oy = 0;
     mgrt_status st = MGRT_OK;
     if (iters == 0) {
-        // no smoothing: the residual of `in` and its restriction in one march over in and f (one ring of
-        // halo, strips of two rows on the levels whose march is a latency chain)
-        // (8-byte elements: strips of four rows with two planes prefetched, for registers)
-        const bool small = latency_bound_level(*fine);
-        oy = (small ? 16 : 32) - 2;
+        // no smoothing: the residual of `in` and its restriction.  On bandwidth-bound levels as one march
+        // over in and f (one ring of halo; 8-byte elements: two planes prefetched, for registers); on the
+        // others, where a march costs its step latency whatever it computes, tile by tile through LDS
+        // (nothing passes through r, no seams).
+        if (latency_bound_level(*fine)) {
+            if (!(parts & 1))
+                return MGRT_OK;
+            // narrow planes: one launch through LDS (65^3: 7 us against 5 + 5); in between the two streaming
+            // kernels, the residual passing through r (257^3: 39 + 14 us against 100 for a march)
+            if ((long long)fine->nx * fine->ny < 100LL * 100LL)
+                return residual_restrict_tiles(fine, coarse, rc, in, f, hs);
+            if (mgrt_status st2 = Step<R>::residual(fine, r, in, f, 1, nullptr, 0, fine->ny, s))
+                return st2;
+            return Step<R>::restrict_(fine, coarse, rc, r, 0, coarse->ny, s);
+        }
+        oy = 32 - 2;
         if (parts & 1)
-            st = small ? launch<R, 0, 2, 8, 4, true, false, 1, false, true>(fine, nullptr, in, f, omega, zcount, hs, r, coarse, nullptr, rc)
-                       : launch<R, 0, 4, 8, sizeof(R) == 4 ? 4 : 2, true, false, 1, false, true>(fine, nullptr, in, f, omega, zcount, hs, r, coarse, nullptr, rc);
+            st = launch<R, 0, 4, 8, sizeof(R) == 4 ? 4 : 2, true, false, 1, false, true>(fine, nullptr, in, f, omega, zcount, hs, r, coarse, nullptr, rc);
     } else if constexpr (sizeof(R) == 4) {
         constexpr int SR = 4, NW = 8, H = 5;
         oy = NW * SR - 2 * H;

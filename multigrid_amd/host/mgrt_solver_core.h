@@ -47,8 +47,9 @@ public:
     bool cycle(real *u, const real *f, const Dims &n, real omega, int a1, int a2, int v, int cycles);
     bool fmg(real *out, const real *f, const Dims &n, real omega, int a1, int a2, int v, int iters);
 
-    // Not in the reference (one device, one queue): from here on this solver is one rank of `t` (one process
-    // or thread per GPU) and cycle() / fmg() take this rank's rows of a 3D box `globalHeight` rows high, cut
+    // Not in the reference (one device, one queue): from here on this solver is one rank of `t`: one process
+    // per GPU (the runtime under it is a process-wide singleton bound to one device by mgrt_init; several
+    // solver threads of one process share that device and are for the callback transport only) and cycle() / fmg() take this rank's rows of a 3D box `globalHeight` rows high, cut
     // along y (mgrt_slab_plan_* of libmgrt.so).  Levels of at most `crossover` points are solved whole on
     // every rank.  Box domains only.  The step kernels above keep working on whole arrays.
     void distribute(const mgrt_transport &t, int globalHeight, long long crossover);

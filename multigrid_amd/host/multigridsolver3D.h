@@ -50,7 +50,8 @@ public:
     // Not in the reference: relax all z planes (see SolverCore::fullZRange) / graph replay.
     void setFullZRange(bool on) { m_core.fullZRange = on; }
     void setUseGraph(bool on) { m_core.useGraph = on; }
-    // Not in the reference: make this solver one rank of several (one process or thread per GPU).  iterate,
+    // Not in the reference: make this solver one rank of several, one process per GPU (solver threads of one process all
+    // run on the device mgrt_init selected: good for the callback transport on one GPU, not for RCCL).  iterate,
     // mg and fmg then take this rank's rows, slabRows(...) of them, of a box `globalHeight` rows high that is
     // cut along y; every rank calls them together.  Results are bitwise those of one GPU.
     void distribute(const mgrt_transport &t, int globalHeight, long long crossover = 129LL * 129 * 257)

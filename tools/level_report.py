@@ -38,7 +38,7 @@ def main():
     bottoms = [i for i, r in enumerate(rows) if "k_bottom_cycle" in r[2]]
     if bottoms:
         # V-cycles: every cycle restricts the same number of times before its one bottom launch
-        depth = sum("k_restrict" in r[2] for r in rows[:bottoms[-1]]) // len(bottoms)
+        depth = sum("k_restrict" in r[2] or "k_residual_restrict3d" in r[2] for r in rows[:bottoms[-1]]) // len(bottoms)
         end = bottoms[-1]
         while depth > 0 and end + 1 < len(rows):
             end += 1
@@ -71,6 +71,8 @@ def main():
                 level = 0
                 continue
             fam, byts = "residual", 3 * pts[level] * w
+        elif k == "k_residual_restrict3d":
+            fam, byts = "residual + restrict (tiles)", (2 * pts[level] + pts[level + 1]) * w
         elif k == "k_restrict" and seam_next:
             # the coarse rows on the seams between the sweep's rows of tiles (22 fine rows each): three fine
             # rows read and one coarse row written per seam
@@ -88,7 +90,7 @@ def main():
         agg[(level, fam, byts)].append(dur)
         if k != "k_smooth3d_fused":
             seam_next = False
-        if k == "k_restrict":
+        if k in ("k_restrict", "k_residual_restrict3d"):
             level += 1
     print("3D %d^3, %d-byte elements; achieved = algorithmic bytes / mean kernel time; peak %.0f GB/s" % (n, w, PEAK))
     print("%-5s %-8s %-34s %6s %10s %10s %7s" % ("level", "extent", "kernel", "calls", "mean us", "GB/s", "% peak"))
@@ -97,7 +99,7 @@ def main():
         gbs = byts / mean / 1e3 if byts else 0.0
         print("%-5d %-8s %-34s %6d %10.1f %10.0f %6.1f%%" % (lv, "%d^3" % sizes[lv], fam, len(v), mean, gbs, 100 * gbs / PEAK))
     per_level = defaultdict(float)
-    cycles = max(1, max(len(v) for (lv, fam, _), v in agg.items() if lv == 0 and fam.startswith("restrict")))
+    cycles = max(1, max(len(v) for (lv, fam, _), v in agg.items() if lv == 0 and "restrict" in fam and "history" not in fam))
     for (lv, fam, byts), v in agg.items():
         if "history" not in fam:
             per_level[lv] += sum(v) / cycles
