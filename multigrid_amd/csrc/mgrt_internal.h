@@ -127,6 +127,14 @@ mgrt_status restrict_rows(const mgrt_grid *fine, const mgrt_grid *coarse, float 
 mgrt_status restrict_rows(const mgrt_grid *fine, const mgrt_grid *coarse, double *rc, const double *rf, int j0, int jstep,
                           int nrows, hipStream_t hs);
 
+// Rows [cylo, cyhi) of the coarse array rc = Restrict(f - A in) as one march over in and f (mgrt_smooth_fused.hip),
+// on whole grids or y-slabs at even offsets; the fine residual rows around tile seams pass through r, the rest of
+// r is not written.  The fine rows those coarse rows read, and their neighbours, must be held and valid.
+mgrt_status residual_restrict_march(const mgrt_grid *fine, const mgrt_grid *coarse, float *rc, float *r, const float *in,
+                                    const float *f, int cylo, int cyhi, hipStream_t hs);
+mgrt_status residual_restrict_march(const mgrt_grid *fine, const mgrt_grid *coarse, double *rc, double *r, const double *in,
+                                    const double *f, int cylo, int cyhi, hipStream_t hs);
+
 // rc = Restrict(f - A u) on a whole 3D analytic box, tile by tile with the fine residual in LDS only.
 mgrt_status residual_restrict_tiles(const mgrt_grid *fine, const mgrt_grid *coarse, float *rc, const float *u, const float *f,
                                     hipStream_t hs);

@@ -965,8 +965,7 @@ template <class R>
 mgrt_status restrict_rows_impl(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, const R *rf, int j0, int jstep, int nrows,
                                hipStream_t hs)
 {
-    MGRT_REQUIRE(fine->dim == 3 && !fine->cells && !neumann_extension(fine) && fine->y0 == 0 && coarse->y0 == 0,
-                 "restrict_rows: whole 3D analytic boxes only");
+    MGRT_REQUIRE(fine->dim == 3 && !fine->cells && !neumann_extension(fine), "restrict_rows: 3D analytic boxes only");
     if (nrows <= 0)
         return MGRT_OK;
     MGRT_REQUIRE(j0 >= 0 && jstep >= 1 && j0 + (long long)(nrows - 1) * jstep < coarse->ny, "restrict_rows: rows outside the grid");

@@ -434,6 +434,32 @@ mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1,
                     return st;
                 restricted = true;
             }
+        } else if (c1 - c0 > 2 && !latency_bound_level(L.g) && L.g.nx % 2 == 1 && L.g.gny % 2 == 1 && L.nz % 2 == 1 &&
+                   L.nz >= 5 && L.g.y0 % 2 == 0 && plane_offsets_fit(&L.g, sizeof(R))) {
+            // Bandwidth-bound level without a residual from the sweep (double precision): residual and
+            // restriction as one march, the fine residual in registers.  The coarse rows in between read owned
+            // rows only and are formed while the halo of the unknown travels; the first and the last follow
+            // from a few residual rows of their own.
+            if (!halo_valid)
+                if (mgrt_status st = exchange_begin(p, L, cur))
+                    return st;
+            if (mgrt_status st = residual_restrict_march(&L.g, cg, crhs, (R *)L.r, cur, f, c0 + 1, c1 - 1, p->stream))
+                return st;
+            if (!halo_valid) {
+                if (mgrt_status st = exchange_end(p))
+                    return st;
+                halo_valid = true;
+            }
+            const int f0 = 2 * (c0 + cg->y0) - L.g.y0, f1 = 2 * (c1 - 1 + cg->y0) - L.g.y0; // their fine rows
+            if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, f0 - 1 > rlo ? f0 - 1 : rlo, f0 + 2, s))
+                return st;
+            if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, f1 - 1, f1 + 2 < rhi ? f1 + 2 : rhi, s))
+                return st;
+            if (mgrt_status st = K<R>::restrict_(&L.g, cg, crhs, (const R *)L.r, c0, c0 + 1, s))
+                return st;
+            if (mgrt_status st = K<R>::restrict_(&L.g, cg, crhs, (const R *)L.r, c1 - 1, c1, s))
+                return st;
+            restricted = true;
         } else if (!halo_valid && L.own1 - L.own0 > 2) {
             if (mgrt_status st = exchange_begin(p, L, cur))
                 return st;

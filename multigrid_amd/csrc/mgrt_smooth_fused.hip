@@ -68,6 +68,7 @@ struct CoarseField {
     void *rc;      // RST: the coarse right-hand side to write
     long long pitch, slab;
     int nx, ny, nz, y0;
+    int ylo, yhi;  // RST: the coarse rows (of the coarse array) this launch writes
 };
 
 // dot(real4, real4) as the reference evaluates it: left to right in R
@@ -228,9 +229,10 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int r = 2 * j + 1, l = ly0 + r, y = y0 + r, yg = y + g.y0;
+            const int cj = (yg >> 1) - cf.y0; // row of the coarse array
             const bool own = xin && y >= 0 && y < g.ny && lane >= HX && lane < kWave - HX && (x & 1) == 0 &&
-                             ((l >= H + 2 && l < NW * SR - H) || (l == H && ty == 0));
-            cof[j] = own ? ((unsigned)(x >> 1) + (unsigned)cf.pitch * (unsigned)((yg >> 1) - cf.y0)) * (unsigned)sizeof(R) : kDrop;
+                             ((l >= H + 2 && l < NW * SR - H) || (l == H && ty == 0)) && cj >= cf.ylo && cj < cf.yhi;
+            cof[j] = own ? ((unsigned)(x >> 1) + (unsigned)cf.pitch * (unsigned)cj) * (unsigned)sizeof(R) : kDrop;
             injl[j] = x == 0 || x == g.nx - 1 || yg == 0 || yg == g.gny - 1;
         }
 #pragma unroll
@@ -768,7 +770,8 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
 template <class R, int ITERS, int SR, int NW, int PD, bool RES = false, bool COR = false, int STAGES = 1, bool MAP = false,
           bool RST = false>
 mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, int zcount, hipStream_t hs,
-                   R *res = nullptr, const mgrt_grid *cg = nullptr, const R *e = nullptr, R *rc = nullptr)
+                   R *res = nullptr, const mgrt_grid *cg = nullptr, const R *e = nullptr, R *rc = nullptr, int cylo = 0,
+                   int cyhi = 1 << 30)
 {
     constexpr int H = 2 * ITERS * STAGES + (RES ? 1 : 0), OX = kWave - 2 * (H + (RST ? 1 : 0)), OY = NW * SR - 2 * H;
     static_assert(OY > 0, "tile has no interior");
@@ -781,6 +784,7 @@ mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega,
     if (COR || RST) {
         cf.e = e, cf.rc = rc, cf.pitch = cg->pitch, cf.slab = cg->slab;
         cf.nx = cg->nx, cf.ny = cg->ny, cf.nz = cg->nz, cf.y0 = cg->y0;
+        cf.ylo = cylo > 0 ? cylo : 0, cf.yhi = cyhi < cg->ny ? cyhi : cg->ny;
     }
     if (omega == (R)1)
         k_smooth3d_fused<R, ITERS, SR, NW, PD, true, RES, COR, STAGES, MAP, RST><<<grid, NW * STAGES * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, cf);
@@ -843,6 +847,9 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
         const int rows_small = (iters == 1 ? 16 : sizeof(R) == 4 ? 16 : 24) - 2 * h;
         const int big = ntx * ((g->ny + 32 - 2 * h - 1) / (32 - 2 * h)), thin = ntx * ((g->ny + rows_small - 1) / rows_small);
         small = 16 * big <= 9 * runtime().num_cu && thin <= runtime().num_cu;
+        // 8-byte elements, two iterations: that shape is one stage of twelve two-row strips
+        if (small && sizeof(R) == 8 && iters == 2)
+            return launch<R, 2, 2, 12, 3>(g, out, in, f, omega, zcount, hs);
     }
     if (g->cells) { // any domain: classes from the byte map (8-byte elements: strips of two rows, for registers)
         if constexpr (sizeof(R) == 4) {
@@ -870,16 +877,14 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
     // 257^3).  Where tiles of six strips a stage still give every tile a CU of its own, those are taken:
     // three wavefronts a SIMD instead of four (129^3: 49 vs 55 us, 65^3: 29 vs 35 and 37 for one stage,
     // 33^3: 20 vs 22 and 23).
-    if constexpr (sizeof(R) == 4) { // 16 wavefronts a block leave 128 registers a lane: tight for 8-byte elements
-        if (small) {
-            if (!two_stage_six_strips(*g))
-                return launch<R, 1, 2, 8, 4, false, false, 2>(g, out, in, f, omega, zcount, hs);
-            return (long long)g->nx * g->ny >= 100LL * 100LL ? launch<R, 1, 2, 6, 2, false, false, 2>(g, out, in, f, omega, zcount, hs)
-                                                             : launch<R, 1, 2, 6, 4, false, false, 2>(g, out, in, f, omega, zcount, hs);
-        }
+    // (8-byte elements: 124-126 registers with four planes prefetched, under the 128 that 16 wavefronts leave)
+    if (small) {
+        if (!two_stage_six_strips(*g))
+            return launch<R, 1, 2, 8, 4, false, false, 2>(g, out, in, f, omega, zcount, hs);
+        return (long long)g->nx * g->ny >= 100LL * 100LL ? launch<R, 1, 2, 6, 2, false, false, 2>(g, out, in, f, omega, zcount, hs)
+                                                         : launch<R, 1, 2, 6, 4, false, false, 2>(g, out, in, f, omega, zcount, hs);
     }
-    return small ? launch<R, 2, 2, sizeof(R) == 4 ? 8 : 12, 3>(g, out, in, f, omega, zcount, hs)
-                 : launch<R, 2, C::SR2, C::NW2, C::PF2>(g, out, in, f, omega, zcount, hs);
+    return launch<R, 2, C::SR2, C::NW2, C::PF2>(g, out, in, f, omega, zcount, hs);
 }
 
 // out = S^iters(u + 4*P(e)): the correction feeding the post-smoother without a pass of its own.
@@ -1017,7 +1022,56 @@ mgrt_status smooth_sweep_residual_restrict(const mgrt_grid *fine, const mgrt_gri
     return parts & 2 ? restrict_rows(fine, coarse, rc, r, oy / 2, oy / 2, nseams, hs) : MGRT_OK;
 }
 
+// The residual + restriction march on a y-slab: rows [cylo, cyhi) of the coarse array from the residual of
+// `in` on the fine rows around them (every fine row a coarse row reads must lie inside the arrays with a
+// row to spare on either side, and hold valid values).
+template <class R>
+mgrt_status residual_restrict_march_impl(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, R *r, const R *in, const R *f,
+                                         int cylo, int cyhi, hipStream_t hs)
+{
+    const char *who = "residual_restrict_march";
+    MGRT_REQUIRE(fine->dim == 3 && !fine->cells && !neumann_extension(fine) && fine->nx % 2 == 1 && fine->gny % 2 == 1 &&
+                     fine->nz % 2 == 1 && fine->nz >= 5 && fine->y0 % 2 == 0 && plane_offsets_fit(fine, sizeof(R)),
+                 "%s: 3D analytic boxes with odd extents, slabs at even offsets", who);
+    MGRT_REQUIRE(0 <= cylo && cylo <= cyhi && cyhi <= coarse->ny, "%s: coarse rows [%d,%d) outside [0,%d)", who, cylo, cyhi,
+                 coarse->ny);
+    if (cylo == cyhi)
+        return MGRT_OK;
+    // fine rows 2j - 1 .. 2j + 1 of a coarse row j inside the grid, and their stencils, must be held
+    const int flo = 2 * (cylo + coarse->y0) - fine->y0, fhi = 2 * (cyhi - 1 + coarse->y0) - fine->y0;
+    MGRT_REQUIRE(flo >= (flo + fine->y0 == 0 ? 0 : 2) && fhi <= fine->ny - 1 - (fhi + fine->y0 == fine->gny - 1 ? 0 : 2),
+                 "%s: the fine slab does not hold the rows coarse rows [%d,%d) read", who, cylo, cyhi);
+    // strips of two rows where tiles of four-row strips would leave most CUs without one (thin slabs)
+    const int ntx = (fine->nx + 59) / 60;
+    const bool thin = 2 * ntx * ((fine->ny + 29) / 30) <= runtime().num_cu;
+    const int OY = (thin ? 16 : 32) - 2;
+    if (mgrt_status st = thin ? launch<R, 0, 2, 8, 4, true, false, 1, false, true>(fine, nullptr, in, f, (R)1, fine->nz, hs, r, coarse,
+                                                                                nullptr, rc, cylo, cyhi)
+                              : launch<R, 0, 4, 8, sizeof(R) == 4 ? 4 : 2, true, false, 1, false, true>(
+                                    fine, nullptr, in, f, (R)1, fine->nz, hs, r, coarse, nullptr, rc, cylo, cyhi))
+        return st;
+    // coarse rows on the seams between rows of tiles: fine row k * OY of the arrays, k = 1 ..
+    const int nty = (fine->ny + OY - 1) / OY, base = fine->y0 / 2 - coarse->y0;
+    int k0 = 1, k1 = nty - 1;
+    while (k0 <= k1 && base + k0 * (OY / 2) < cylo) ++k0;
+    while (k1 >= k0 && base + k1 * (OY / 2) >= cyhi) --k1;
+    return restrict_rows(fine, coarse, rc, r, base + k0 * (OY / 2), OY / 2, k1 - k0 + 1, hs);
+}
+
 } // namespace
+
+namespace mgrt {
+mgrt_status residual_restrict_march(const mgrt_grid *fine, const mgrt_grid *coarse, float *rc, float *r, const float *in,
+                                    const float *f, int cylo, int cyhi, hipStream_t hs)
+{
+    return residual_restrict_march_impl<float>(fine, coarse, rc, r, in, f, cylo, cyhi, hs);
+}
+mgrt_status residual_restrict_march(const mgrt_grid *fine, const mgrt_grid *coarse, double *rc, double *r, const double *in,
+                                    const double *f, int cylo, int cyhi, hipStream_t hs)
+{
+    return residual_restrict_march_impl<double>(fine, coarse, rc, r, in, f, cylo, cyhi, hs);
+}
+} // namespace mgrt
 
 extern "C" mgrt_status mgrt_smooth_sweep_residual_restrict_f32(const mgrt_grid *fine, const mgrt_grid *coarse, float *out,
                                                                float *rc, float *r, const float *in, const float *f,

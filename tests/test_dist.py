@@ -72,6 +72,11 @@ GPU_CASES = [
     # wide planes: the slabs of level 0 take the sweep that applies the correction itself
     (2, (9, 641, 513), "f32", 1.0, 2, 2, 1, 2, True, 5 * 321 * 257),
     (2, (9, 641, 513), "f32", 0.9, 1, 3, 2, 1, False, 5 * 321 * 257),
+    # wide planes where no sweep carries the residual (double precision; no pre-smoothing): residual and
+    # restriction as one march over the slab, the coarse rows at its ends from residual rows of their own
+    (2, (9, 641, 513), "f64", 1.0, 2, 2, 1, 2, True, 5 * 321 * 257),
+    (3, (9, 961, 321), "f64", 0.9, 2, 2, 2, 1, True, 5 * 481 * 161),
+    (2, (9, 641, 513), "f32", 1.0, 0, 2, 1, 2, True, 5 * 321 * 257),
 ]
 
 

@@ -28,6 +28,7 @@ for n in 513 1025; do
   python3 tools/level_report.py "$out/trace${n}d" $n 8 > "$out/per_level_${n}f64.txt" || exit 1
 done
 timeout -k 10 200 python3 tools/kbench.py > "$out/kbench513.txt" 2>&1 || exit 1
+rm -f "$out/pmc_traffic.json"
 bash tools/pmc.sh "$out/pmc" fetch,write || exit 1
 python3 tools/pmc_summary.py "$out/pmc" > "$out/pmc_fetch_write_kbench513.txt" || exit 1
 python3 tools/pmc_traffic.py "$out/pmc" 513 f32 "$out/pmc_traffic.json" || exit 1
