@@ -135,6 +135,12 @@ mgrt_status residual_restrict_march(const mgrt_grid *fine, const mgrt_grid *coar
 mgrt_status residual_restrict_march(const mgrt_grid *fine, const mgrt_grid *coarse, double *rc, double *r, const double *in,
                                     const double *f, int cylo, int cyhi, hipStream_t hs);
 
+// out = S^2(in) and rows [cylo, cyhi) of the coarse array rc = Restrict(f - A out): the restriction-carrying sweep
+// on a whole grid or a y-slab at an even offset (4-byte elements).  cylo == cyhi: the sweep alone.
+mgrt_status sweep_residual_restrict_rows(const mgrt_grid *fine, const mgrt_grid *coarse, float *out, float *rc, float *r,
+                                         const float *in, const float *f, float omega, int zcount, int cylo, int cyhi,
+                                         hipStream_t hs);
+
 // rc = Restrict(f - A u) on a whole 3D analytic box, tile by tile with the fine residual in LDS only.
 mgrt_status residual_restrict_tiles(const mgrt_grid *fine, const mgrt_grid *coarse, float *rc, const float *u, const float *f,
                                     hipStream_t hs);

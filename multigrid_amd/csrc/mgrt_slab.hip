@@ -355,9 +355,11 @@ int zcount_of(const mgrt_slab_plan *p, const mgrt_slab_plan::Level &L)
 // owned rows (the rows next to them were smoothed from halo rows that are stale by then).
 // `zero`: the field is known to be zero everywhere and `cur` has not been cleared; the first sweep then
 // reads no input at all (a null input stands for zeros), as in the one-GPU plan.
+// With `cg` (and `res`) that sweep also restricts that residual: rows [c0, c1) of the coarse array crhs, the fine
+// residual staying in registers (only the rows next to tile seams pass through res).
 template <class R>
 mgrt_status smooth(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, R *&cur, R *&alt, const R *f, R omega, int a, bool &halo_valid,
-                   R *res = nullptr, bool zero = false)
+                   R *res = nullptr, bool zero = false, const mgrt_grid *cg = nullptr, R *crhs = nullptr, int c0 = 0, int c1 = 0)
 {
     mgrt_stream s = (mgrt_stream)p->stream;
     for (int left = a; left > 0;) {
@@ -367,7 +369,15 @@ mgrt_status smooth(mgrt_slab_plan *p, mgrt_slab_plan::Level &L, R *&cur, R *&alt
             if (mgrt_status st = exchange(p, L, cur))
                 return st;
         zero = false;
-        if (res && left == n) {
+        if (res && cg && left == n) {
+            if constexpr (sizeof(R) == 4) {
+                if (mgrt_status st = sweep_residual_restrict_rows(&L.g, cg, alt, crhs, res, in, f, omega, zcount_of(p, L), c0, c1,
+                                                                  p->stream))
+                    return st;
+            } else {
+                return fail(MGRT_E_UNSUPPORTED, "mgrt_slab_plan: no restriction-carrying sweep for this element size");
+            }
+        } else if (res && left == n) {
             if (mgrt_status st = K<R>::sweep_res(&L.g, alt, res, in, f, omega, n, zcount_of(p, L), s))
                 return st;
         } else if (mgrt_status st = K<R>::sweep(&L.g, alt, in, f, omega, n, zcount_of(p, L), s))
@@ -397,20 +407,41 @@ mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1,
     // As on one GPU, the last pre-smoothing sweep of a bandwidth-bound level in single precision carries
     // the residual pass along (slabs too thin for strips of four rows: measured slower than the two kernels).
     const bool res_in_sweep = a1 > 0 && v > 0 && sizeof(R) == 4 && !latency_bound_level(L.g) && L.own1 - L.own0 > 2;
-    if (mgrt_status st = smooth<R>(p, L, cur, alt, f, omega, a1, halo_valid, res_in_sweep ? (R *)L.r : nullptr, u_is_zero))
-        return st;
     const bool last = l + 1 == p->ndist;
+    // where the restricted residual goes: this rank's rows [c0, c1) of the next level
+    const mgrt_grid *cg = last ? &p->cgrid : &p->lv[l + 1].g;
+    R *crhs = last ? (R *)p->c_rhs : (R *)p->lv[l + 1].rhs;
+    const int c0 = last ? p->crow0[p->rank] : p->lv[l + 1].own0, c1 = last ? p->crow1[p->rank] : p->lv[l + 1].own1;
+    // ... and the restriction of the coarse rows in between as well, where that sweep does two iterations: the
+    // residual then stays in registers (the first and the last coarse row follow from residual rows of their own)
+    const bool fusable = c1 - c0 > 2 && L.g.nx % 2 == 1 && L.g.gny % 2 == 1 && L.nz % 2 == 1 && L.nz >= 5 && L.g.y0 % 2 == 0 &&
+                         plane_offsets_fit(&L.g, sizeof(R));
+    const bool rst_in_sweep = res_in_sweep && fusable && a1 % 2 == 0;
+    if (mgrt_status st = smooth<R>(p, L, cur, alt, f, omega, a1, halo_valid, res_in_sweep ? (R *)L.r : nullptr, u_is_zero,
+                                   rst_in_sweep ? cg : nullptr, crhs, c0 + 1, c1 - 1))
+        return st;
     for (int it = 0; it < v; ++it) {
         // residual on the owned rows and one more on each side: what the restriction reads.  The rows
         // whose stencil stays inside the owned rows are formed while the halo of the unknown travels,
         // the two rows at either end afterwards.
         const int rlo = L.y0 > 0 ? L.own0 - 1 : L.own0, rhi = L.y1 < L.gny ? L.own1 + 1 : L.own1;
-        // where the restricted residual goes: this rank's rows [c0, c1) of the next level
-        const mgrt_grid *cg = last ? &p->cgrid : &p->lv[l + 1].g;
-        R *crhs = last ? (R *)p->c_rhs : (R *)p->lv[l + 1].rhs;
-        const int c0 = last ? p->crow0[p->rank] : p->lv[l + 1].own0, c1 = last ? p->crow1[p->rank] : p->lv[l + 1].own1;
+        const int f0 = 2 * (c0 + cg->y0) - L.g.y0, f1 = 2 * (c1 - 1 + cg->y0) - L.g.y0; // fine rows of coarse rows c0, c1 - 1
         bool restricted = false;
-        if (res_in_sweep && it == 0) {
+        if (rst_in_sweep && it == 0) {
+            // the sweep restricted the coarse rows in between; the first and the last need the neighbours' rows
+            if (mgrt_status st = exchange(p, L, cur))
+                return st;
+            halo_valid = true;
+            if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, f0 - 1 > rlo ? f0 - 1 : rlo, f0 + 2, s))
+                return st;
+            if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, f1 - 1, f1 + 2 < rhi ? f1 + 2 : rhi, s))
+                return st;
+            if (mgrt_status st = K<R>::restrict_(&L.g, cg, crhs, (const R *)L.r, c0, c0 + 1, s))
+                return st;
+            if (mgrt_status st = K<R>::restrict_(&L.g, cg, crhs, (const R *)L.r, c1 - 1, c1, s))
+                return st;
+            restricted = true;
+        } else if (res_in_sweep && it == 0) {
             // The sweep left the rows in between; the two at either end need the neighbours' rows.  While
             // those travel, the coarse rows that only read what the sweep left are restricted.
             if (mgrt_status st = exchange_begin(p, L, cur))
@@ -434,8 +465,7 @@ mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1,
                     return st;
                 restricted = true;
             }
-        } else if (c1 - c0 > 2 && !latency_bound_level(L.g) && L.g.nx % 2 == 1 && L.g.gny % 2 == 1 && L.nz % 2 == 1 &&
-                   L.nz >= 5 && L.g.y0 % 2 == 0 && plane_offsets_fit(&L.g, sizeof(R))) {
+        } else if (fusable && !latency_bound_level(L.g)) {
             // Bandwidth-bound level without a residual from the sweep (double precision): residual and
             // restriction as one march, the fine residual in registers.  The coarse rows in between read owned
             // rows only and are formed while the halo of the unknown travels; the first and the last follow
@@ -450,7 +480,6 @@ mgrt_status iterate(mgrt_slab_plan *p, int l, R *u, const R *f, R omega, int a1,
                     return st;
                 halo_valid = true;
             }
-            const int f0 = 2 * (c0 + cg->y0) - L.g.y0, f1 = 2 * (c1 - 1 + cg->y0) - L.g.y0; // their fine rows
             if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, f0 - 1 > rlo ? f0 - 1 : rlo, f0 + 2, s))
                 return st;
             if (mgrt_status st = K<R>::residual(&L.g, (R *)L.r, cur, f, 1, nullptr, f1 - 1, f1 + 2 < rhi ? f1 + 2 : rhi, s))

@@ -1022,33 +1022,49 @@ mgrt_status smooth_sweep_residual_restrict(const mgrt_grid *fine, const mgrt_gri
     return parts & 2 ? restrict_rows(fine, coarse, rc, r, oy / 2, oy / 2, nseams, hs) : MGRT_OK;
 }
 
-// The residual + restriction march on a y-slab: rows [cylo, cyhi) of the coarse array from the residual of
-// `in` on the fine rows around them (every fine row a coarse row reads must lie inside the arrays with a
-// row to spare on either side, and hold valid values).
+// The restriction-carrying sweep (iters == 2, 4-byte elements) or the residual + restriction march
+// (iters == 0, out unused) on a whole grid or a y-slab: rows [cylo, cyhi) of the coarse array from the
+// residual of the smoothed field (of `in`) on the fine rows around them.  Every fine row those coarse rows
+// read, its neighbours and (iters == 2) the four halo rows two iterations consume must lie inside the arrays
+// and hold valid values on entry.
 template <class R>
-mgrt_status residual_restrict_march_impl(const mgrt_grid *fine, const mgrt_grid *coarse, R *rc, R *r, const R *in, const R *f,
-                                         int cylo, int cyhi, hipStream_t hs)
+mgrt_status fused_residual_restrict_rows(const mgrt_grid *fine, const mgrt_grid *coarse, R *out, R *rc, R *r, const R *in,
+                                         const R *f, R omega, int iters, int zcount, int cylo, int cyhi, hipStream_t hs)
 {
-    const char *who = "residual_restrict_march";
+    const char *who = "fused_residual_restrict_rows";
     MGRT_REQUIRE(fine->dim == 3 && !fine->cells && !neumann_extension(fine) && fine->nx % 2 == 1 && fine->gny % 2 == 1 &&
                      fine->nz % 2 == 1 && fine->nz >= 5 && fine->y0 % 2 == 0 && plane_offsets_fit(fine, sizeof(R)),
                  "%s: 3D analytic boxes with odd extents, slabs at even offsets", who);
+    MGRT_REQUIRE(iters == 0 || (iters == 2 && sizeof(R) == 4 && out), "%s: no iteration, or two with 4-byte elements", who);
     MGRT_REQUIRE(0 <= cylo && cylo <= cyhi && cyhi <= coarse->ny, "%s: coarse rows [%d,%d) outside [0,%d)", who, cylo, cyhi,
                  coarse->ny);
-    if (cylo == cyhi)
+    if (cylo == cyhi && iters == 0)
         return MGRT_OK;
-    // fine rows 2j - 1 .. 2j + 1 of a coarse row j inside the grid, and their stencils, must be held
-    const int flo = 2 * (cylo + coarse->y0) - fine->y0, fhi = 2 * (cyhi - 1 + coarse->y0) - fine->y0;
-    MGRT_REQUIRE(flo >= (flo + fine->y0 == 0 ? 0 : 2) && fhi <= fine->ny - 1 - (fhi + fine->y0 == fine->gny - 1 ? 0 : 2),
-                 "%s: the fine slab does not hold the rows coarse rows [%d,%d) read", who, cylo, cyhi);
-    // strips of two rows where tiles of four-row strips would leave most CUs without one (thin slabs)
-    const int ntx = (fine->nx + 59) / 60;
-    const bool thin = 2 * ntx * ((fine->ny + 29) / 30) <= runtime().num_cu;
-    const int OY = (thin ? 16 : 32) - 2;
-    if (mgrt_status st = thin ? launch<R, 0, 2, 8, 4, true, false, 1, false, true>(fine, nullptr, in, f, (R)1, fine->nz, hs, r, coarse,
-                                                                                nullptr, rc, cylo, cyhi)
-                              : launch<R, 0, 4, 8, sizeof(R) == 4 ? 4 : 2, true, false, 1, false, true>(
-                                    fine, nullptr, in, f, (R)1, fine->nz, hs, r, coarse, nullptr, rc, cylo, cyhi))
+    if (cylo < cyhi) {
+        // fine rows 2j - 1 .. 2j + 1 of a coarse row j, their stencils and the sweep's halo, as far as the grid goes
+        const int need = 2 + 2 * iters;
+        const int glo = 2 * (cylo + coarse->y0) - need, ghi = 2 * (cyhi - 1 + coarse->y0) + need; // global fine rows
+        MGRT_REQUIRE((glo > 0 ? glo : 0) >= fine->y0 && (ghi < fine->gny - 1 ? ghi : fine->gny - 1) <= fine->y0 + fine->ny - 1,
+                     "%s: the fine slab does not hold the rows coarse rows [%d,%d) read", who, cylo, cyhi);
+    }
+    int OY;
+    mgrt_status st;
+    if (iters == 0) {
+        // strips of two rows where tiles of four-row strips would leave most CUs without one (thin slabs)
+        const int ntx = (fine->nx + 59) / 60;
+        const bool thin = 2 * ntx * ((fine->ny + 29) / 30) <= runtime().num_cu;
+        OY = (thin ? 16 : 32) - 2;
+        st = thin ? launch<R, 0, 2, 8, 4, true, false, 1, false, true>(fine, nullptr, in, f, (R)1, fine->nz, hs, r, coarse, nullptr, rc,
+                                                                    cylo, cyhi)
+                  : launch<R, 0, 4, 8, sizeof(R) == 4 ? 4 : 2, true, false, 1, false, true>(fine, nullptr, in, f, (R)1, fine->nz, hs, r,
+                                                                                         coarse, nullptr, rc, cylo, cyhi);
+    } else if constexpr (sizeof(R) == 4) {
+        OY = 32 - 2 * 5;
+        st = launch<R, 2, 4, 8, 4, true, false, 1, false, true>(fine, out, in, f, omega, zcount, hs, r, coarse, nullptr, rc, cylo, cyhi);
+    } else {
+        return fail(MGRT_E_UNSUPPORTED, "%s: no kernel", who);
+    }
+    if (st != MGRT_OK)
         return st;
     // coarse rows on the seams between rows of tiles: fine row k * OY of the arrays, k = 1 ..
     const int nty = (fine->ny + OY - 1) / OY, base = fine->y0 / 2 - coarse->y0;
@@ -1064,12 +1080,18 @@ namespace mgrt {
 mgrt_status residual_restrict_march(const mgrt_grid *fine, const mgrt_grid *coarse, float *rc, float *r, const float *in,
                                     const float *f, int cylo, int cyhi, hipStream_t hs)
 {
-    return residual_restrict_march_impl<float>(fine, coarse, rc, r, in, f, cylo, cyhi, hs);
+    return fused_residual_restrict_rows<float>(fine, coarse, nullptr, rc, r, in, f, 1.0f, 0, fine->nz, cylo, cyhi, hs);
 }
 mgrt_status residual_restrict_march(const mgrt_grid *fine, const mgrt_grid *coarse, double *rc, double *r, const double *in,
                                     const double *f, int cylo, int cyhi, hipStream_t hs)
 {
-    return residual_restrict_march_impl<double>(fine, coarse, rc, r, in, f, cylo, cyhi, hs);
+    return fused_residual_restrict_rows<double>(fine, coarse, nullptr, rc, r, in, f, 1.0, 0, fine->nz, cylo, cyhi, hs);
+}
+mgrt_status sweep_residual_restrict_rows(const mgrt_grid *fine, const mgrt_grid *coarse, float *out, float *rc, float *r,
+                                         const float *in, const float *f, float omega, int zcount, int cylo, int cyhi,
+                                         hipStream_t hs)
+{
+    return fused_residual_restrict_rows<float>(fine, coarse, out, rc, r, in, f, omega, 2, zcount, cylo, cyhi, hs);
 }
 } // namespace mgrt
 
