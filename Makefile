@@ -11,7 +11,7 @@ ARCH     ?= gfx950
 HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Iinclude -Wall -Wno-unused-function
 CSRC      = multigrid_amd/csrc
 LIB       = multigrid_amd/libmgrt.so
-LIB_SRCS  = $(CSRC)/mgrt_runtime.hip $(CSRC)/mgrt_kernels.hip $(CSRC)/mgrt_smooth_fused.hip $(CSRC)/mgrt_smooth2d.hip $(CSRC)/mgrt_bottom.hip $(CSRC)/mgrt_plan.hip $(CSRC)/mgrt_slab.hip
+LIB_SRCS  = $(CSRC)/mgrt_runtime.hip $(CSRC)/mgrt_kernels.hip $(CSRC)/mgrt_smooth_fused.hip $(CSRC)/mgrt_smooth_pair.hip $(CSRC)/mgrt_smooth2d.hip $(CSRC)/mgrt_bottom.hip $(CSRC)/mgrt_plan.hip $(CSRC)/mgrt_slab.hip
 LIB_OBJS  = $(LIB_SRCS:.hip=.o)
 
 all: lib oracle host

@@ -147,6 +147,12 @@ mgrt_status residual_restrict_tiles(const mgrt_grid *fine, const mgrt_grid *coar
 mgrt_status residual_restrict_tiles(const mgrt_grid *fine, const mgrt_grid *coarse, double *rc, const double *u, const double *f,
                                     hipStream_t hs);
 
+// out = S^2(in) on a latency-bound 3D analytic box (whole or y-slab) as two stages of one iteration each, two
+// planes a time step (mgrt_smooth_pair.hip; 4-byte elements); six_strips: tiles of 64 x 12 instead of 64 x 16.  in
+// may be null (zeros).
+mgrt_status smooth_sweep_pair(const mgrt_grid *g, float *out, const float *in, const float *f, float omega, int zcount,
+                              bool six_strips, hipStream_t hs);
+
 // out = S^iters(in) on a 2D analytic-box grid, iters 1 or 2 (mgrt_smooth2d.hip); in may be null.
 // res (optional) receives the residual of out or, when cg is given without e, its restriction to
 // the coarse grid cg; e with its coarse grid cg (optional) makes the input in + 4*P(e).

@@ -873,16 +873,22 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
         return small ? launch<R, 1, 2, 8, 4>(g, out, in, f, omega, zcount, hs)
                      : launch<R, 1, C::SR1, C::NW1, C::PF1>(g, out, in, f, omega, zcount, hs);
     // Latency-bound levels: strips of two rows, as two stages of one iteration each: a step of the march
-    // then costs what one wavefront issues in it, and a wavefront issues half as much (105 vs 119 us at
-    // 257^3).  Where tiles of six strips a stage still give every tile a CU of its own, those are taken:
-    // three wavefronts a SIMD instead of four (129^3: 49 vs 55 us, 65^3: 29 vs 35 and 37 for one stage,
-    // 33^3: 20 vs 22 and 23).
-    // (8-byte elements: 124-126 registers with four planes prefetched, under the 128 that 16 wavefronts leave)
+    // then costs what the wavefronts of a SIMD issue in it, and a wavefront issues half as much (105 vs
+    // 119 us at 257^3).  Where tiles of six strips a stage still give every tile a CU of its own, those are
+    // taken: three wavefronts a SIMD instead of four (129^3: 49 vs 55 us, 65^3: 29 vs 35 and 37 for one
+    // stage, 33^3: 20 vs 22 and 23).  4-byte elements: the form that takes two planes a time step
+    // (mgrt_smooth_pair.hip: 257^3 107 -> 95 us); 8-byte elements: one plane a step, 124-126 registers with
+    // four planes prefetched, under the 128 that 16 wavefronts leave.
     if (small) {
-        if (!two_stage_six_strips(*g))
+        const bool six = two_stage_six_strips(*g), wide = (long long)g->nx * g->ny >= 100LL * 100LL;
+        if constexpr (sizeof(R) == 4) {
+            if (wide) // below that its longer lag costs what its shorter steps gain (33^3: 18 against 16 us)
+                return smooth_sweep_pair(g, out, in, f, omega, zcount, six, hs);
+        }
+        if (!six)
             return launch<R, 1, 2, 8, 4, false, false, 2>(g, out, in, f, omega, zcount, hs);
-        return (long long)g->nx * g->ny >= 100LL * 100LL ? launch<R, 1, 2, 6, 2, false, false, 2>(g, out, in, f, omega, zcount, hs)
-                                                         : launch<R, 1, 2, 6, 4, false, false, 2>(g, out, in, f, omega, zcount, hs);
+        return wide ? launch<R, 1, 2, 6, 2, false, false, 2>(g, out, in, f, omega, zcount, hs)
+                    : launch<R, 1, 2, 6, 4, false, false, 2>(g, out, in, f, omega, zcount, hs);
     }
     return launch<R, 2, C::SR2, C::NW2, C::PF2>(g, out, in, f, omega, zcount, hs);
 }

@@ -16,7 +16,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "multigrid_amd", "csrc", "mgrt_smooth_fused.hip")
+SRCS = [os.path.join(ROOT, "multigrid_amd", "csrc", n) for n in ("mgrt_smooth_fused.hip", "mgrt_smooth_pair.hip")]
 
 
 def regs(tok):
@@ -31,12 +31,14 @@ def regs(tok):
 
 
 def main():
+    text = []
     with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "fused.s")
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-               "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out, SRC] + sys.argv[1:]
-        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
-        text = open(out).read().splitlines()
+        for src in SRCS:
+            out = os.path.join(tmp, os.path.basename(src) + ".s")
+            cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                   "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out, src] + sys.argv[1:]
+            subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+            text += open(out).read().splitlines()
     kernel, bad, nk, loops = None, [], 0, 0
     in_asm, depth2 = False, False
     loop_lines = []

@@ -56,7 +56,9 @@ def main():
             continue
         k, targs = m.group(1), [a.strip() for a in m.group(2).split(",")]
         dur = (t1 - t0) * 1e-3
-        if k == "k_smooth3d_fused":
+        if k == "k_smooth3d_fused_pair":  # two stages of one iteration each, two planes a step
+            fam, byts = "sweep x2", 3 * pts[level] * w
+        elif k == "k_smooth3d_fused":
             res, cor = targs[6] == "true", targs[7] == "true"
             if cor:
                 level -= 1
