@@ -504,7 +504,9 @@ def main():
                 kernel = ("k_smooth3d_fused", "3D sweep of 2 red-black iterations")
                 fields = {0: "float" if w == 4 else "double", 1: "2", 5: "true", 6: "false", 7: "false"}
                 if w == 4 and 100 * 100 <= shape[1] * shape[2] <= 300 * 300:
-                    fields.update({1: "1", 8: "2"})  # latency-bound level: two stages of one iteration each
+                    # latency-bound level: two stages of one iteration each, two planes a time step
+                    kernel = ("k_smooth3d_fused_pair", kernel[1] + " (two stages, two planes a step)")
+                    fields = {0: "float", 3: "true"}
             # Every launch between its own pair of events on the stream it runs on, after a few untimed ones
             # (the first launches on freshly allocated arrays run 10-30 % long).  For the headline workload the
             # launches that follow the sweep on the finest level of a cycle are issued in between (the seam rows'

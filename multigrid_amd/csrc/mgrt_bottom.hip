@@ -50,6 +50,17 @@ template <int DIM> __device__ __forceinline__ int box_class(const Lvl &L, const 
 
 __device__ __forceinline__ bool border_class(int t) { return t == MGRT_CELL_DIRICHLET || t == MGRT_CELL_NEUMANN; }
 
+// floor(i / d) and i mod d for 0 <= i < 2^21, d >= 1 without the forty-instruction integer division: (i + 0.5) / d lies
+// at least 0.5 / d away from every integer, the hardware reciprocal is good to one unit in the last place and the
+// product rounds once more, which together displace it by less than (i / d) * 2^-22.
+struct FastDiv {
+    int d;
+    float rcp;
+    __device__ __forceinline__ explicit FastDiv(int d_) : d(d_), rcp(__builtin_amdgcn_rcpf((float)d_)) {}
+    __device__ __forceinline__ int quot(int i) const { return (int)(((float)i + 0.5f) * rcp); }
+    __device__ __forceinline__ void split(int i, int &q, int &r) const { q = quot(i), r = i - q * d; }
+};
+
 template <class R> __device__ __forceinline__ R dot4b(R a0, R a1, R a2, R a3, R b0, R b1, R b2, R b3)
 {
     return a0 * b0 + a1 * b1 + a2 * b2 + a3 * b3;
@@ -124,8 +135,10 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
             // passes * zcount.  Every point is computed by the same expression from the same values
             // as in the pass-by-pass schedule below.
             const int ncol = hx * L.ny, npass = 2 * iters;
-            const int p = tid / ncol, idx = tid - p * ncol;
-            const int y = idx / hx, x = 2 * (idx % hx) + ((p + y) & 1);
+            int p, idx, y, xh;
+            FastDiv(ncol).split(tid, p, idx);
+            FastDiv(hx).split(idx, y, xh);
+            const int x = 2 * xh + ((p + y) & 1);
             const bool active = p < npass && x < L.nx;
             const int lat = !active ? (int)MGRT_CELL_OUTER
                                     : y == 0 ? face[2] : y == L.ny - 1 ? face[3] : x == 0 ? face[0] : x == L.nx - 1 ? face[1] : -1;
@@ -157,8 +170,11 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
         }
         for (int it = 0; it < 2 * iters; ++it) {
             const int odd = it & 1;
+            const FastDiv by_hx(hx);
             for (int idx = tid; idx < hx * L.ny; idx += kThreads) {
-                const int y = idx / hx, x = 2 * (idx % hx) + ((odd + y) & 1);
+                int y, xh;
+                by_hx.split(idx, y, xh);
+                const int x = 2 * xh + ((odd + y) & 1);
                 if (x >= L.nx)
                     continue;
                 if (DIM == 2) { // true red-black point update, mg_0.cl:29-40,52-98
@@ -226,8 +242,11 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
         const Lvl L = level(l);
         const R *u = u_of(l), *f = u + L.n;
         R *r = u_of(l) + 2 * L.n;
+        const FastDiv by_plane(L.s), by_row(L.nx);
         for (int i = tid; i < L.n; i += kThreads) {
-            const int x = i % L.nx, y = (i / L.nx) % L.ny, z = i / L.s;
+            int x, y, z, inplane;
+            by_plane.split(i, z, inplane);
+            by_row.split(inplane, y, x);
             const int t = box_class<DIM>(L, face, x, y, z);
             R v = 0;
             if (t == MGRT_CELL_INNER)
@@ -246,8 +265,11 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
         const R *rf = u_of(l) + 2 * Lf.n;
         R *e = u_of(l + 1), *rc = e + Lc.n;
         const int p = Lf.p, s = Lf.s;
+        const FastDiv by_plane(Lc.s), by_row(Lc.nx);
         for (int d = tid; d < Lc.n; d += kThreads) {
-            const int i = d % Lc.nx, j = (d / Lc.nx) % Lc.ny, k = d / Lc.s;
+            int i, j, k, inplane;
+            by_plane.split(d, k, inplane);
+            by_row.split(inplane, j, i);
             const int x = 2 * i, y = 2 * j, z = DIM == 3 ? 2 * k : 0;
             const R *c = rf + x + p * y + s * z;
             const bool on_face = x == 0 || x == Lf.nx - 1 || y == 0 || y == Lf.ny - 1 ||
@@ -288,8 +310,11 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
         R *u = u_of(l);
         const R *e = u_of(l + 1);
         const int cp = Lc.p, cs = Lc.s;
+        const FastDiv by_plane(Lf.s), by_row(Lf.nx);
         for (int d = tid; d < Lf.n; d += kThreads) {
-            const int x = d % Lf.nx, y = (d / Lf.nx) % Lf.ny, z = d / Lf.s;
+            int x, y, z, inplane;
+            by_plane.split(d, z, inplane);
+            by_row.split(inplane, y, x);
             const int ci = x / 2, cj = y / 2, ck = z / 2;
             const int ci1 = ci + 1 < Lc.nx ? ci + 1 : ci;
             const int cj1 = cj + 1 < Lc.ny ? cj + 1 : cj;
