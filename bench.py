@@ -439,8 +439,93 @@ def main():
             torch.cuda.synchronize()
 
     phase("kernel")
+
+    def time_kernel(u):
+        # The dominant kernel of the workload: the pre-smoothing launch of the finest level, the longest
+        # of the cycle, timed alone with events on the stream it runs on (on arrays of its own).
+        g = _lib.grid(shape, faces=faces)
+        dof = 1.0
+        for s in shape:
+            dof *= s
+        work = torch.empty_like(u)
+        if len(shape) == 2:
+            cshape = tuple((s + 1) // 2 for s in shape)
+            gc = _lib.grid(cshape, faces=faces)
+            rc = torch.empty(cshape, dtype=tdt, device=dev)
+            launch = lambda a, b: _lib.smooth_sweep_residual_restrict(g, gc, a, rc, b, f, 1.0, 2)
+            alg_bytes = (3.0 * dof + float(rc.numel())) * w
+            kernel = ("k_smooth2d_cols", "2D sweep of 2 red-black iterations that also writes the restricted residual")
+            fields = {0: "float" if w == 4 else "double", 1: "2", 5: "2"}
+        elif w == 4 and _lib.restrict_sweep_supported(g, tdt, 2):
+            # the headline workload: the sweep also forms the residual and restricts it to the coarse grid
+            cshape = tuple((s + 1) // 2 for s in shape)
+            gc = _lib.grid(cshape, faces=faces)
+            rc = torch.empty(cshape, dtype=tdt, device=dev)
+            ec = torch.zeros(cshape, dtype=tdt, device=dev)
+            resid = torch.empty_like(u)  # only the rows next to tile seams pass through it
+
+            def part(mask, a, b):  # the operation is two launches: 1 = the sweep kernel, 2 = the seam rows' restriction
+                _lib.sweep_parts(mask)
+                try:
+                    _lib.smooth_sweep_residual_restrict(g, gc, a, rc, b, f, 1.0, 2, r=resid)
+                finally:
+                    _lib.sweep_parts(3)
+            launch = lambda a, b: part(1, a, b)
+            alg_bytes = (3.0 * dof + float(rc.numel())) * w  # read u, read f, write the smoothed field, write the coarse rhs
+            kernel = ("k_smooth3d_fused", "3D sweep of 2 red-black iterations with the residual pass and its restriction")
+            fields = {0: "float", 1: "2", 5: "true", 6: "true", 7: "false", 10: "true"}
+        else:
+            launch = lambda a, b: _lib.smooth_sweep(g, a, b, f, 1.0, 2)
+            alg_bytes = 3.0 * dof * w  # read u, read f, write the smoothed field
+            kernel = ("k_smooth3d_fused", "3D sweep of 2 red-black iterations")
+            fields = {0: "float" if w == 4 else "double", 1: "2", 5: "true", 6: "false", 7: "false"}
+            if w == 4 and 100 * 100 <= shape[1] * shape[2] <= 300 * 300:
+                # latency-bound level: two stages of one iteration each, two planes a time step
+                kernel = ("k_smooth3d_fused_pair", kernel[1] + " (two stages, two planes a step)")
+                fields = {0: "float", 3: "true"}
+        # Every launch between its own pair of events on the stream it runs on, after untimed ones (the first
+        # launches on freshly allocated arrays run 10-30 % long, the first tens of milliseconds after start-up 1-2 %).  For the headline workload the
+        # launches that follow the sweep on the finest level of a cycle are issued in between (the seam rows'
+        # restriction, the sweep on the corrected field), so that the sweep finds memory as it does in the
+        # cycle; a third event after them closes the finest level's share of a cycle.
+        follow = None
+        if kernel[1].endswith("its restriction"):
+            def follow(a, b):  # a: the smoothed field just written, b: the array the cycle continues in
+                part(2, a, b)
+                _lib.correct_smooth_sweep(g, gc, b, a, ec, f, 1.0, 2)
+        reps, warm = (20, 20) if dof < 6e8 else (6, 2)  # some tens of milliseconds of untimed launches either way
+        pairs = []
+        for i in range(warm + reps):
+            a, b = (work, u) if follow or i % 2 == 0 else (u, work)
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record(stream)
+            launch(a, b)
+            e1.record(stream)
+            if follow:
+                follow(a, b)
+                e2.record(stream)
+            pairs.append((e0, e1, e2))
+        pairs[-1][2 if follow else 1].synchronize()
+        torch.cuda.synchronize()
+        t_kernel = sum(x.elapsed_time(y) for x, y, _ in pairs[warm:]) * 1e-3 / reps
+        level0 = None
+        if follow:
+            t_l0 = sum(x.elapsed_time(z) for x, _, z in pairs[warm:]) * 1e-3 / reps
+            l0_bytes = 2.0 * (3.0 * dof + float(rc.numel())) * w
+            level0 = {"ms": t_l0 * 1e3, "compulsory_bytes": l0_bytes, "achieved": l0_bytes / t_l0 / 1e9, "unit": "GB/s",
+                      "frac": l0_bytes / t_l0 / 1e9 / HBM_PEAK_GBS,
+                      "what": "the finest level's three launches of a cycle back to back between events: sweep x2 with "
+                              "residual and restriction (u, f in; u, coarse rhs out), the seam rows' restriction, sweep x2 "
+                              "on u + 4 P(e) (u, e, f in; u out); every field counted once per launch that needs it"}
+        return {"t": t_kernel, "level0": level0, "alg_bytes": alg_bytes, "kernel": kernel, "fields": fields, "dof": dof}
+
     with torch.cuda.stream(stream):
         if world == 1:
+            # The kernel first: the cycles then start on a device that has been busy for some tens of milliseconds.
+            # Straight after start-up the first ten to twenty cycles run 1-2 % long (W = 5: 1.60-1.61 ms a cycle in the
+            # timed region at 513^3, W >= 30: 1.583, the per-cycle median either way), which says something about
+            # the device's start-up and nothing about the cycle.
+            timed = time_kernel(torch.zeros_like(f))
             plan = _lib.Plan(shape, tdt, faces=faces, zfull=True, use_graph=not args.no_graph)
             r0 = plan.vcycle(u, f, ncycles=0, history=True)[0]
             plan.vcycle(u, f, 1.0, 2, 2, 1, args.warmup)
@@ -463,86 +548,11 @@ def main():
                 spread = {"min": each[0], "median": each[len(each) // 2], "max": each[-1], "steps": len(each),
                           "what": "every cycle between its own events, a second run of the same steps after the timed region"}
             plan.close()
-
-        if rank == 0:
-            # The dominant kernel of the workload: the pre-smoothing launch of the finest level, the longest
-            # of the cycle, timed alone with events on the stream it runs on.
-            g = _lib.grid(shape, faces=faces)
-            dof = 1.0
-            for s in shape:
-                dof *= s
-            work = torch.empty_like(u)
-            if len(shape) == 2:
-                cshape = tuple((s + 1) // 2 for s in shape)
-                gc = _lib.grid(cshape, faces=faces)
-                rc = torch.empty(cshape, dtype=tdt, device=dev)
-                launch = lambda a, b: _lib.smooth_sweep_residual_restrict(g, gc, a, rc, b, f, 1.0, 2)
-                alg_bytes = (3.0 * dof + float(rc.numel())) * w
-                kernel = ("k_smooth2d_cols", "2D sweep of 2 red-black iterations that also writes the restricted residual")
-                fields = {0: "float" if w == 4 else "double", 1: "2", 5: "2"}
-            elif w == 4 and _lib.restrict_sweep_supported(g, tdt, 2):
-                # the headline workload: the sweep also forms the residual and restricts it to the coarse grid
-                cshape = tuple((s + 1) // 2 for s in shape)
-                gc = _lib.grid(cshape, faces=faces)
-                rc = torch.empty(cshape, dtype=tdt, device=dev)
-                ec = torch.zeros(cshape, dtype=tdt, device=dev)
-                resid = torch.empty_like(u)  # only the rows next to tile seams pass through it
-
-                def part(mask, a, b):  # the operation is two launches: 1 = the sweep kernel, 2 = the seam rows' restriction
-                    _lib.sweep_parts(mask)
-                    try:
-                        _lib.smooth_sweep_residual_restrict(g, gc, a, rc, b, f, 1.0, 2, r=resid)
-                    finally:
-                        _lib.sweep_parts(3)
-                launch = lambda a, b: part(1, a, b)
-                alg_bytes = (3.0 * dof + float(rc.numel())) * w  # read u, read f, write the smoothed field, write the coarse rhs
-                kernel = ("k_smooth3d_fused", "3D sweep of 2 red-black iterations with the residual pass and its restriction")
-                fields = {0: "float", 1: "2", 5: "true", 6: "true", 7: "false", 10: "true"}
-            else:
-                launch = lambda a, b: _lib.smooth_sweep(g, a, b, f, 1.0, 2)
-                alg_bytes = 3.0 * dof * w  # read u, read f, write the smoothed field
-                kernel = ("k_smooth3d_fused", "3D sweep of 2 red-black iterations")
-                fields = {0: "float" if w == 4 else "double", 1: "2", 5: "true", 6: "false", 7: "false"}
-                if w == 4 and 100 * 100 <= shape[1] * shape[2] <= 300 * 300:
-                    # latency-bound level: two stages of one iteration each, two planes a time step
-                    kernel = ("k_smooth3d_fused_pair", kernel[1] + " (two stages, two planes a step)")
-                    fields = {0: "float", 3: "true"}
-            # Every launch between its own pair of events on the stream it runs on, after a few untimed ones
-            # (the first launches on freshly allocated arrays run 10-30 % long).  For the headline workload the
-            # launches that follow the sweep on the finest level of a cycle are issued in between (the seam rows'
-            # restriction, the sweep on the corrected field), so that the sweep finds memory as it does in the
-            # cycle; a third event after them closes the finest level's share of a cycle.
-            follow = None
-            if kernel[1].endswith("its restriction"):
-                def follow(a, b):  # a: the smoothed field just written, b: the array the cycle continues in
-                    part(2, a, b)
-                    _lib.correct_smooth_sweep(g, gc, b, a, ec, f, 1.0, 2)
-            reps, warm = (20, 5) if dof < 6e8 else (6, 2)
-            pairs = []
-            for i in range(warm + reps):
-                a, b = (work, u) if follow or i % 2 == 0 else (u, work)
-                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-                e0.record(stream)
-                launch(a, b)
-                e1.record(stream)
-                if follow:
-                    follow(a, b)
-                    e2.record(stream)
-                pairs.append((e0, e1, e2))
-            pairs[-1][2 if follow else 1].synchronize()
-            torch.cuda.synchronize()
-            t_kernel = sum(x.elapsed_time(y) for x, y, _ in pairs[warm:]) * 1e-3 / reps
-            level0 = None
-            if follow:
-                t_l0 = sum(x.elapsed_time(z) for x, _, z in pairs[warm:]) * 1e-3 / reps
-                l0_bytes = 2.0 * (3.0 * dof + float(rc.numel())) * w
-                level0 = {"ms": t_l0 * 1e3, "compulsory_bytes": l0_bytes, "achieved": l0_bytes / t_l0 / 1e9, "unit": "GB/s",
-                          "frac": l0_bytes / t_l0 / 1e9 / HBM_PEAK_GBS,
-                          "what": "the finest level's three launches of a cycle back to back between events: sweep x2 with "
-                                  "residual and restriction (u, f in; u, coarse rhs out), the seam rows' restriction, sweep x2 "
-                                  "on u + 4 P(e) (u, e, f in; u out); every field counted once per launch that needs it"}
+        elif rank == 0:
+            timed = time_kernel(u)
 
     if rank == 0:
+        t_kernel, level0, alg_bytes, kernel, fields, dof = (timed[k] for k in ("t", "level0", "alg_bytes", "kernel", "fields", "dof"))
         achieved = alg_bytes / t_kernel / 1e9
         traffic = pmc_traffic(kernel[0], n, dtname, fields)
         # algorithmic bytes of a whole unfused V(2,2) cycle: 22 N w + 3 Nc w per level, 16 N w coarsest
@@ -580,7 +590,7 @@ def main():
             **({"step_ms": spread} if spread else {}),
         }
         if world == 1 and not args.no_cpu:
-            del f, u, work
+            del f, u, timed
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(args.config, shape)
         if os.environ.get("MGRT_BENCH_EARLIER"):

@@ -95,6 +95,9 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
     auto u_of = [&](int l) { return base + s_geo[l][3]; };
     const int tid = threadIdx.x;
     const int(&face)[6] = A.face;
+    // The classes of the two z faces as values of their own: selected by address inside a loop (face[z == 0 ? 4 : 5]) they
+    // become a vector load from the argument segment, a trip to memory in the middle of a time step.
+    const int face_z0 = A.face[4], face_z1 = A.face[5];
 
     {
         // loads in batches of 8 per thread: a plain loop would wait for each load in turn
@@ -146,14 +149,28 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
             const bool gather = lat < 0;
             const int oxp = gather ? 1 : 0, oxm = gather ? -1 : 0, oyp = gather ? L.p : 0, oym = gather ? -L.p : 0;
             const int ztop = L.nz - 1;
+            // what a step costs is what the wavefronts of a SIMD issue in it: one pointer per operand stream, advanced by a
+            // plane a step, and the column's class on its first, inner and last plane worked out beforehand
+            const int cls_first = lat >= 0 ? lat : face_z0, cls_inner = lat >= 0 ? lat : (int)MGRT_CELL_INNER,
+                      cls_last = lat >= 0 ? lat : face_z1;
+            // Byte offsets into the LDS block, one per operand stream, each made opaque once so that the compiler keeps
+            // seven finished addresses and advances them (it otherwise keeps partial sums and adds the level's base again
+            // before every read).  o_own is plane t - p of the column: used only once that plane exists.
+            const int plane_bytes = L.s * (int)sizeof(R);
+            int o_own = (int)((u + col - L.s * p - base) * (long)sizeof(R));
+            int o_xp = o_own + oxp * (int)sizeof(R), o_xm = o_own + oxm * (int)sizeof(R), o_yp = o_own + oyp * (int)sizeof(R),
+                o_ym = o_own + oym * (int)sizeof(R), o_up = o_own + plane_bytes, o_f = o_own + L.n * (int)sizeof(R);
+            asm volatile("" : "+v"(o_own), "+v"(o_xp), "+v"(o_xm), "+v"(o_yp), "+v"(o_ym), "+v"(o_up), "+v"(o_f));
+            auto at = [&](int off) -> R & { return *reinterpret_cast<R *>(smem + off); };
             R below = 0;
             for (int t = 0; t < L.zcount + npass - 1; ++t) {
                 const int z = t - p;
                 if (active && z >= 0 && z < L.zcount) {
-                    const int b = col + L.s * z;
-                    const R xp = u[b + oxp], xm = u[b + oxm], yp = u[b + oyp], ym = u[b + oym];
-                    const R above = u[col + L.s * (z < ztop ? z + 1 : ztop)], own = u[b], fz = f[b];
-                    const int cls = lat >= 0 ? lat : (z == 0 ? face[4] : z == ztop ? face[5] : (int)MGRT_CELL_INNER);
+                    const R xp = at(o_xp), xm = at(o_xm), yp = at(o_yp), ym = at(o_ym);
+                    // the plane above the last one is the last one itself (the array that follows u in LDS is read and dropped)
+                    const R own = at(o_own), up = at(o_up), fz = at(o_f);
+                    const R above = z < ztop ? up : own;
+                    const int cls = z == 0 ? cls_first : z == ztop ? cls_last : cls_inner;
                     const R val = (1.0 / 6.0) * (xp + xm + yp + ym + above + below - fz);
                     R gs;
                     if (omega_is_one)
@@ -161,9 +178,11 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
                     else
                         gs = val * omega + (1.0 - omega) * own;
                     const R next = cls == MGRT_CELL_INNER ? gs : (cls == MGRT_CELL_DIRICHLET ? fz : own);
-                    u[b] = next;
+                    at(o_own) = next;
                     below = next;
                 }
+                o_own += plane_bytes, o_xp += plane_bytes, o_xm += plane_bytes, o_yp += plane_bytes, o_ym += plane_bytes,
+                    o_up += plane_bytes, o_f += plane_bytes;
                 __syncthreads();
             }
             return;
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(kThreads) void k_bottom_cycle(BottomArgs A, R *u_ou
                 R below = 0;
                 for (int z = 0; z < L.zcount; ++z) {
                     const Ahead nx = fetch(z + 1);
-                    const int t = lat >= 0 ? lat : (z == 0 ? face[4] : z == ztop ? face[5] : (int)MGRT_CELL_INNER);
+                    const int t = lat >= 0 ? lat : (z == 0 ? face_z0 : z == ztop ? face_z1 : (int)MGRT_CELL_INNER);
                     const R val = (1.0 / 6.0) * (sum4 + above + below - fz);
                     R gs;
                     if (omega_is_one)
