@@ -111,9 +111,15 @@ int mgrt_smooth_sweep_residual_restrict_supported(const mgrt_grid *fine, int ele
 /* Measurement aid, no counterpart in the reference.  mgrt_smooth_sweep_residual_restrict_f32 in 3D is two
  * launches (the sweep, then the restriction of the coarse rows on its tile seams); a harness that times
  * the sweep kernel alone between its own events selects with `mask` which of them the following calls of
- * this process issue: bit 0 the sweep, bit 1 the seam restriction.  Returns the previous mask; the
- * default, 3, is the only setting that computes the documented result. */
+ * this process issue: bit 0 the sweep, bit 1 the seam restriction.  Bit 2 makes the fused 3D sweeps launch a
+ * plane with more tiles than the device runs at once as one grid instead of band by band (same values,
+ * for comparing the two).  Returns the previous mask; the default, 3, is the only setting that computes
+ * the documented result the documented way. */
 int mgrt_sweep_parts(int mask);
+/* Measurement aid, no counterpart in the reference: the number of launches (bands of tile rows) the most
+ * recent fused 3D sweep kernel of this process was issued as; 1 unless the plane has more tiles than the
+ * device holds at once.  A harness divides an operation's bytes and time by it to get figures per launch. */
+int mgrt_last_sweep_launches(void);
 
 #define MGRT_DECLARE_KERNELS(R, S)                                                                 \
     /* One colour pass of the weighted Gauss-Seidel smoother, in place.  Replaces                 \

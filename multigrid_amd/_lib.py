@@ -69,7 +69,7 @@ _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "u
             "stream_create", "stream_destroy", "sync", "zero", "box_cells_host",
             "plan_create", "plan_destroy", "plan_levels", "plan_level_dims", "plan_set_cells",
             "plan_vcycle", "plan_fmg", "correct_smooth_sweep_supported", "smooth_sweep_residual_restrict_supported",
-            "sumsq_noalloc_f32", "sweep_parts",
+            "sumsq_noalloc_f32", "sweep_parts", "last_sweep_launches",
             "rccl_unique_id", "rccl_selftest", "slab_plan_create", "slab_plan_destroy", "slab_plan_distributed_levels",
             "slab_plan_uses_graph", "slab_plan_rows", "slab_plan_vcycle", "slab_plan_fmg"]
 SYMBOLS = ["mgrt_" + n for n in _RUNTIME] + ["mgrt_%s_%s" % (k, s) for k in _KERNELS for s in ("f32", "f64")]
@@ -121,6 +121,8 @@ def load():
         getattr(lib, "mgrt_" + name).argtypes = [p]
     lib.mgrt_sweep_parts.restype = i
     lib.mgrt_sweep_parts.argtypes = [i]
+    lib.mgrt_last_sweep_launches.restype = i
+    lib.mgrt_last_sweep_launches.argtypes = []
     lib.mgrt_correct_smooth_sweep_supported.restype = i
     lib.mgrt_correct_smooth_sweep_supported.argtypes = [G, i, i]
     lib.mgrt_smooth_sweep_residual_restrict_supported.restype = i
@@ -167,6 +169,8 @@ def init(device=0):
     global _initialised
     check(load().mgrt_init(device))
     _initialised = device
+    if os.environ.get("MGRT_ONE_GRID"):  # development: A/B of the band-wise launches of large planes
+        load().mgrt_sweep_parts(3 | 4)
 
 
 def grid(shape, cells=None, faces=ALL_DIRICHLET, y0=0, gny=None, pitch=None, slab=None, neumann=0):
@@ -252,8 +256,14 @@ def smooth_sweep_residual_restrict(fine, coarse, out, rc, inp, f, omega, iters, 
 
 def sweep_parts(mask):
     """mgrt_sweep_parts: which launches of the two-launch 3D sweep with restriction are issued (bit 0 the sweep,
-    bit 1 the seam restriction); returns the previous mask.  For timing a kernel alone."""
+    bit 1 the seam restriction; bit 2: large planes as one grid instead of bands); returns the previous mask.  For timing
+    a kernel alone."""
     return load().mgrt_sweep_parts(mask)
+
+
+def last_sweep_launches():
+    """mgrt_last_sweep_launches: how many launches (bands of tile rows) the last fused 3D sweep kernel was issued as."""
+    return load().mgrt_last_sweep_launches()
 
 
 def smooth_sweep_residual(g, out, r, inp, f, omega, iters, zcount=None, stream=None):

@@ -32,6 +32,8 @@ struct Runtime {
     int num_cu = 0;
     double *static_partials = nullptr; // device address of the fixed scratch array of mgrt_sumsq_noalloc_f32
     int sweep_parts = 3;               // mgrt_sweep_parts: which launches of a two-launch sweep operation are issued
+    bool sweep_bands = true;           // mgrt_sweep_parts bit 2 clears it: a large plane in one launch instead of bands
+    int last_sweep_launches = 0;       // launches the last fused 3D sweep kernel call was split into
 };
 Runtime &runtime();
 mgrt_status require_init();

@@ -142,10 +142,13 @@ mgrt_status mgrt_shutdown(void)
 int mgrt_sweep_parts(int mask)
 {
     Runtime &rt = runtime();
-    const int before = rt.sweep_parts;
+    const int before = rt.sweep_parts | (rt.sweep_bands ? 0 : 4);
     rt.sweep_parts = mask & 3;
+    rt.sweep_bands = !(mask & 4);
     return before;
 }
+
+int mgrt_last_sweep_launches(void) { return runtime().last_sweep_launches; }
 
 mgrt_status mgrt_device_name(char *buf, int len)
 {

@@ -322,6 +322,7 @@ mgrt_status launch_pair(const mgrt_grid *g, R *out, const R *in, const R *f, R o
         k_smooth3d_fused_pair<R, NW, PD, true><<<grid, NW * 2 * kWave, lds, hs>>>(*g, in, out, f, omega, zcount, ntx);
     else
         k_smooth3d_fused_pair<R, NW, PD, false><<<grid, NW * 2 * kWave, lds, hs>>>(*g, in, out, f, omega, zcount, ntx);
+    runtime().last_sweep_launches = 1;
     MGRT_HIP(hipGetLastError());
     return MGRT_OK;
 }

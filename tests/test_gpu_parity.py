@@ -853,3 +853,89 @@ def test_3d_residual_restriction_march_matches_oracle(dev, mgo, shape, dt):
             bad = np.argwhere(gc_host.view(bits) != want_c.view(bits))
             raise AssertionError((shape, faces, "rc", len(bad), bad[:8].tolist(), sorted(set(bad[:, 1].tolist()))[:12],
                                   sorted(set(bad[:, 2].tolist()))[:12], sorted(set(bad[:, 0].tolist()))[:12]))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
+def test_large_planes_swept_in_bands_match_oracle_and_one_launch(dev, mgo, dt):
+    """A plane with more tiles than the device runs at once is swept as several launches, a band of tile rows
+    each.  1025 x 1025 columns: every fused 3D sweep (plain, with residual, with residual and restriction, the
+    residual + restriction march, on the corrected field) in bands against the same call as one launch, bit for
+    bit, the plain sweep and the march also against the oracle, and two V(2,2) cycles of a plan against the
+    oracle's."""
+    import torch
+    from multigrid_amd import _lib as L
+    tdt = torch.float32 if dt is np.float32 else torch.float64
+    shape = (5, 1025, 1025)
+    cs = tuple((s + 1) // 2 for s in shape)
+    faces = (2, 3, 2, 2, 3, 2)
+    rng = np.random.default_rng(4242)
+    u = rng.standard_normal(shape).astype(dt)
+    f = rng.standard_normal(shape).astype(dt)
+    e = rng.standard_normal(cs).astype(dt)
+    cell = mgo.box_cells(shape, faces)
+    g, gc = L.grid(shape, faces=faces), L.grid(cs, faces=faces)
+    du, df, de = to_dev(u, dev), to_dev(f, dev), to_dev(e, dev)
+
+    def run(op):
+        outs = []
+        for mask in (3, 3 | 4):  # bands, one grid
+            L.sweep_parts(mask)
+            try:
+                got = op()
+                torch.cuda.synchronize()
+                outs.append(([t.cpu().numpy() for t in got], L.last_sweep_launches()))
+            finally:
+                L.sweep_parts(3)
+        (banded, nb), (whole, nw) = outs
+        assert nb > 1 and nw == 1, (nb, nw)
+        for a, b in zip(banded, whole):
+            assert bits_equal(a, b)
+        return banded
+
+    def plain():
+        o = torch.full(shape, 7.0, dtype=tdt, device=dev)
+        L.smooth_sweep(g, o, du, df, 0.9, 2)
+        return [o]
+
+    def with_residual():
+        o, r = torch.full(shape, 7.0, dtype=tdt, device=dev), torch.full(shape, 8.0, dtype=tdt, device=dev)
+        L.smooth_sweep_residual(g, o, r, du, df, 1.0, 2)
+        return [o, r]
+
+    def with_restriction(iters):
+        o, r = torch.full(shape, 7.0, dtype=tdt, device=dev), torch.full(shape, 8.0, dtype=tdt, device=dev)
+        c = torch.full(cs, 6.0, dtype=tdt, device=dev)
+        L.smooth_sweep_residual_restrict(g, gc, o if iters else None, c, du, df, 1.0, iters, r=r)
+        return [o, c] if iters else [c]
+
+    def corrected():
+        o = torch.full(shape, 7.0, dtype=tdt, device=dev)
+        L.correct_smooth_sweep(g, gc, o, du, de, df, 1.0, 2)
+        return [o]
+
+    want = u.copy()
+    for _ in range(2):
+        for odd in (0, 1):
+            mgo.smooth_pass(cell, want, f, dt(0.9), odd, None)
+    assert bits_equal(run(plain)[0], want)
+    run(with_residual)
+    r = np.zeros_like(u)
+    mgo.residual(cell, r, u, f)
+    want_c = np.empty(cs, dt)
+    mgo.restrict(cell, want_c, r)
+    assert bits_equal(run(lambda: with_restriction(0))[0], want_c)
+    if L.restrict_sweep_supported(g, tdt, 2):
+        run(lambda: with_restriction(2))
+    if L.correct_sweep_supported(g, tdt, 2):
+        run(corrected)
+
+    pshape = (9, 1025, 1025)
+    pf = rng.standard_normal(pshape).astype(dt)
+    ref = np.zeros(pshape, dt)
+    mgo.mg(ref, pf, dt(1.0), 2, 2, 1, 2, True)
+    pu = torch.zeros(pshape, dtype=tdt, device=dev)
+    plan = L.Plan(pshape, tdt, zfull=True, use_graph=True)
+    plan.vcycle(pu, to_dev(pf, dev), 1.0, 2, 2, 1, 2)
+    plan.close()
+    torch.cuda.synchronize()
+    assert bits_equal(pu.cpu().numpy(), ref)

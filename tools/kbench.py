@@ -15,11 +15,14 @@ def main():
     ap.add_argument("--f64", action="store_true")
     ap.add_argument("--only", default="", help="substring filter on kernel names")
     ap.add_argument("--dim", type=int, default=3, help="2: the 2D sweeps on an n x n grid")
+    ap.add_argument("--one-grid", action="store_true", help="fused 3D sweeps: a large plane as one launch instead of band by band")
     args = ap.parse_args()
     import torch
     from multigrid_amd import _lib as L
     torch.cuda.set_device(0)
     L.init(0)
+    if args.one_grid:
+        L.sweep_parts(3 | 4)
     n = args.n
     dt = torch.float64 if args.f64 else torch.float32
     w = 8 if args.f64 else 4

@@ -15,6 +15,38 @@ from collections import defaultdict
 PEAK = 8000.0  # GB/s
 
 
+def fused_args(name):
+    m = re.search(r"k_smooth3d_fused<([^>]*)>", name)
+    return [a.strip() for a in m.group(1).split(",")] if m else None
+
+
+def merge_bands(rows, sizes):
+    """A fused sweep over a plane with more tiles than the device runs at once is issued as several launches of
+    the same kernel, a band of tile rows each: make one row of them (first start to last end).  The tile shape
+    follows from the template arguments <R, ITERS, SR, NW, PD, OMEGA1, RES, COR, STAGES, MAP, RST>; a run of
+    equal launches is complete when its blocks add up to the tiles of a level."""
+    out, run = [], None
+    for t0, t1, name, blocks in rows:
+        a = fused_args(name)
+        if not a:
+            out.append((t0, t1, name))
+            run = None
+            continue
+        if run and run[2] == name:
+            run[1], run[3] = t1, run[3] + blocks
+            out[-1] = (run[0], run[1], name)
+        else:
+            run = [t0, t1, name, blocks]
+            out.append((t0, t1, name))
+        iters, sr, nw, res, stages = int(a[1]), int(a[2]), int(a[3]), a[6] == "true", int(a[8]) if len(a) > 8 else 1
+        rst = len(a) > 10 and a[10] == "true"
+        h = 2 * iters * stages + (1 if res else 0)
+        ox, oy = 64 - 2 * (h + (1 if rst else 0)), nw * sr - 2 * h
+        if any(run[3] == (-(-n // ox)) * (-(-n // oy)) for n in sizes):
+            run = None  # complete: an equal launch that follows is an operation of its own
+    return out
+
+
 def main():
     root = sys.argv[1]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 513
@@ -27,8 +59,13 @@ def main():
     for path in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
         with open(path) as fh:
             for r in csv.DictReader(fh):
-                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
+                             int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))))
     rows.sort()
+    # bench.py times the dominant kernel alone before the cycles; the cycles start with the residual norm of the
+    # history (the first residual kernel that also sums)
+    first = next((i for i, r in enumerate(rows) if re.search(r"k_residual3d_v<[^>]*true>", r[2])), 0)
+    rows = merge_bands(rows[first:], sizes)
     # The last cycle ends where its way up from the last bottom launch is back on level 0: count the
     # restrictions before that launch down and the interpolations after it up.  What bench.py launches
     # after that (its timing loop over the dominant kernel) is not part of a cycle.

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the artefacts kept under profiles/ on a GPU box, into gpurun_out/<tag>/: the bench line
 # alone and under rocprofv3 --kernel-trace --stats, the per-level report, the kernel microbenchmark,
-# separate FETCH_SIZE / WRITE_SIZE passes over it (-> pmc_traffic.json), the other configurations, the
+# separate FETCH_SIZE / WRITE_SIZE passes over it (-> pmc_traffic.json, which the bench lines then read), the other configurations, the
 # solve to tolerance, the one-GPU slab proxy, the bench lines of the other workloads and the 2- and
 # 8-rank rehearsals.  Every GPU step runs under its own time limit; the script stops at the
 # first failure.
@@ -13,7 +13,6 @@ out=$root/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 cd "$root" || exit 1
-timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 > "$out/bench.json" 2> "$out/bench.err" || exit 1
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o bench -- python3 "$root/bench.py" --steps 20 --warmup 3 > "$out/bench_under_rocprof.json" 2> "$out/rocprof.err" || exit 1
 cd "$root" || exit 1
@@ -43,6 +42,9 @@ bash tools/pmc.sh "$out/pmc2d4097" fetch,write --dim 2 --n 4097 || exit 1
 python3 tools/pmc_traffic.py "$out/pmc2d4097" 4097 f32 "$out/pmc_traffic.json" || exit 1
 bash tools/pmc.sh "$out/pmc2d257" fetch,write --dim 2 --n 257 || exit 1
 python3 tools/pmc_traffic.py "$out/pmc2d257" 257 f32 "$out/pmc_traffic.json" || exit 1
+# the counter passes above are what the bench lines take their traffic from
+cp "$out/pmc_traffic.json" profiles/pmc_traffic.json || exit 1
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err" || exit 1
 timeout -k 10 400 python3 tools/bench_configs.py > "$out/configs.txt" 2> "$out/configs.err" || exit 1
 timeout -k 10 400 python3 tools/solve_to_tol.py > "$out/solve_to_tolerance.txt" 2>&1 || exit 1
 timeout -k 10 300 python3 tools/slab_proxy.py > "$out/slab_proxy_513.txt" 2> "$out/slab_proxy.err" || exit 1
