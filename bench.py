@@ -402,7 +402,7 @@ def main():
             lo, hi, a, b = cyc.rows()
             lay = {"rank0_rows_owned": b - a, "halo_rows": 4, "levels_cut": cyc.distributed_levels,
                    "whole_on_every_rank_from_points": args.crossover, "cycle_in_one_graph": cyc.uses_graph,
-                   "transport": note[0]}
+                   "transport": note[0], **({"rccl_version": _lib.rccl_version()} if use_rccl[0] else {})}
             cyc.close()
             return t.item(), ra, rb, lay
 
@@ -607,6 +607,8 @@ def main():
             del f, u, timed
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(args.config, shape)
+        if world > 1 and os.environ.get("MGRT_BENCH_ATTEMPT"):  # every region of this line comes from this attempt
+            out["config"]["attempt"] = ATTEMPTS[int(os.environ["MGRT_BENCH_ATTEMPT"])][0]
         if os.environ.get("MGRT_BENCH_EARLIER"):
             out["config"]["attempts_that_failed"] = os.environ["MGRT_BENCH_EARLIER"]
         print(json.dumps(out), flush=True)

@@ -325,6 +325,9 @@ typedef struct mgrt_slab_plan mgrt_slab_plan;
 
 /* a fresh ncclUniqueId (ncclGetUniqueId); one rank makes it, every rank passes it in mgrt_transport */
 mgrt_status mgrt_rccl_unique_id(unsigned char id[128]);
+/* the version code of the RCCL the library bound (ncclGetVersion: major * 10000 + minor * 100 + patch), for
+ * the record a benchmark keeps; MGRT_E_UNSUPPORTED where RCCL is absent.  No counterpart in the reference. */
+mgrt_status mgrt_rccl_version(int *version);
 /* the RCCL operations a slab plan uses, on a communicator of one rank (so that a single GPU can run it):
  * send/receive with itself, all-gather and all-reduce, queued directly and replayed from a captured graph,
  * results checked.  MGRT_E_UNSUPPORTED where RCCL is absent, MGRT_E_TRANSPORT with the finding otherwise.

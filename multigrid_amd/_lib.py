@@ -70,7 +70,7 @@ _RUNTIME = ["init", "shutdown", "last_error", "device_name", "alloc", "free", "u
             "plan_create", "plan_destroy", "plan_levels", "plan_level_dims", "plan_set_cells",
             "plan_vcycle", "plan_fmg", "correct_smooth_sweep_supported", "smooth_sweep_residual_restrict_supported",
             "sumsq_noalloc_f32", "sweep_parts", "last_sweep_launches",
-            "rccl_unique_id", "rccl_selftest", "slab_plan_create", "slab_plan_destroy", "slab_plan_distributed_levels",
+            "rccl_unique_id", "rccl_version", "rccl_selftest", "slab_plan_create", "slab_plan_destroy", "slab_plan_distributed_levels",
             "slab_plan_uses_graph", "slab_plan_rows", "slab_plan_vcycle", "slab_plan_fmg"]
 SYMBOLS = ["mgrt_" + n for n in _RUNTIME] + ["mgrt_%s_%s" % (k, s) for k in _KERNELS for s in ("f32", "f64")]
 
@@ -413,6 +413,14 @@ def rccl_unique_id():
     buf = (C.c_ubyte * 128)()
     check(load().mgrt_rccl_unique_id(buf))
     return bytes(buf)
+
+
+def rccl_version():
+    """ncclGetVersion of the RCCL the library bound, as 'major.minor.patch'; None where RCCL is absent."""
+    v = C.c_int(0)
+    if load().mgrt_rccl_version(C.byref(v)) != 0:
+        return None
+    return "%d.%d.%d" % (v.value // 10000, v.value // 100 % 100, v.value % 100)
 
 
 def rccl_selftest(stream):

@@ -50,6 +50,7 @@ struct Rccl {
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr; // optional
 };
 constexpr int kNcclChar = 0, kNcclDouble = 8, kNcclSum = 0; // ncclDataType_t / ncclRedOp_t values of rccl.h
 
@@ -76,6 +77,7 @@ mgrt_status rccl(Rccl **out)
             MGRT_SYM(AllGather, "ncclAllGather");
             MGRT_SYM(AllReduce, "ncclAllReduce");
             MGRT_SYM(GetErrorString, "ncclGetErrorString");
+            MGRT_SYM(GetVersion, "ncclGetVersion");
 #undef MGRT_SYM
         }
     });
@@ -744,6 +746,18 @@ mgrt_status vcycle(mgrt_slab_plan *p, R *u, const R *f, R omega, int a1, int a2,
 } // namespace
 
 extern "C" {
+
+mgrt_status mgrt_rccl_version(int *version)
+{
+    MGRT_REQUIRE(version != nullptr, "mgrt_rccl_version: null argument");
+    Rccl *nc = nullptr;
+    if (mgrt_status st = rccl(&nc))
+        return st;
+    if (!nc->GetVersion)
+        return fail(MGRT_E_UNSUPPORTED, "mgrt_rccl_version: this RCCL has no ncclGetVersion");
+    MGRT_NCCL(nc->GetVersion(version));
+    return MGRT_OK;
+}
 
 mgrt_status mgrt_rccl_unique_id(unsigned char id[128])
 {

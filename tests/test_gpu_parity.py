@@ -939,3 +939,18 @@ def test_large_planes_swept_in_bands_match_oracle_and_one_launch(dev, mgo, dt):
     plan.close()
     torch.cuda.synchronize()
     assert bits_equal(pu.cpu().numpy(), ref)
+
+
+def test_quarter_product_in_single_precision_equals_the_double_form_on_all_inputs(dev):
+    """The 2D sweep forms 0.25 * s as one single-precision product where the reference's expression
+    (mg_0.cl:38) is a double product rounded to float: all 2^32 bit patterns through both on the device,
+    compared bit for bit (subnormals, zeros of either sign, infinities, NaN payloads)."""
+    import torch
+    chunk = 1 << 27
+    base = torch.arange(chunk, dtype=torch.int64, device=dev)
+    for k in range(32):
+        bits = (base + k * chunk).to(torch.int32)  # wraps to the pattern's two's complement
+        s = bits.view(torch.float32)
+        single = (s * 0.25).view(torch.int32)
+        double = (s.to(torch.float64) * 0.25).to(torch.float32).view(torch.int32)
+        assert torch.equal(single, double), k
