@@ -148,12 +148,9 @@ def cpu_baseline(name, shape=None, budget_s=12.0):
         share = "; %d threads = this job's share of the host (OMP_NUM_THREADS), whose affinity mask shows %d CPUs" % (
             threads, len(os.sched_getaffinity(0)))
     o.set_num_threads(threads)
+    note = ""
     if faces != (D_,) * 6:
-        # frozen faces: a callback per point would dominate, and their cells are never touched, so the
-        # box rule with a right-hand side of the same shape costs the CPU the same work per point
-        note = " (all-Dirichlet box map: Neumann cells are no-ops in the reference, the work per point is the same)"
-    else:
-        note = ""
+        o.set_box_faces(faces)  # the box with these face types on every level, as RectangularBorderHandler paints it
     f, _ = o.discretize(problem, shape, npdt)
     u = np.zeros(shape, npdt)
     t0 = time.perf_counter()
@@ -164,6 +161,7 @@ def cpu_baseline(name, shape=None, budget_s=12.0):
         o.mg(u, f, npdt(1.0), 2, 2, 1, 1, True)
         reps += 1
     dt_s = (time.perf_counter() - t0) / reps
+    o.set_box_faces(None)
     dof = float(np.prod(shape))
     return {"value": dof / dt_s, "unit": "DOF/s", "cores": threads, "kind": "port",
             "sample": "%d V(2,2) cycles of the same problem at %s (%s, full-z), %.3f s each%s%s"

@@ -98,6 +98,9 @@ void MGO_NAME(set_celltype)(mgo_celltype_fn fn);
  * (inner core, a shell that is Dirichlet on the low-x side and Neumann on the other, outer cells
  * around it).  For cases too large for a callback per point. */
 void MGO_NAME(set_builtin_celltype)(int kind);
+/* The box with these types on its x-lo, x-hi, y-lo, y-hi, z-lo, z-hi faces on every level, shared edges as
+ * box_cells paints them; NULL = back to the all-Dirichlet box. */
+void MGO_NAME(set_box_faces)(const int face[6]);
 /* copy of the cell map the host drivers use on a level of these extents under the active rule */
 void MGO_NAME(copy_level_cells)(int dim, uint8_t *out, int nx, int ny, int nz);
 

@@ -50,6 +50,7 @@ class Oracle:
         self._sig("set_celltype", None, [C.c_void_p])
         self._sig("set_builtin_celltype", None, [i])
         self._sig("copy_level_cells", None, [i, p, i, i, i])
+        self._sig("set_box_faces", None, [p])
         self._sig("num_threads", i, [])
         self._sig("set_num_threads", None, [i])
 
@@ -153,6 +154,11 @@ class Oracle:
         """kind 1: the ball rule compiled into the oracle (no callback per point); 0: back to the box."""
         self._cb = self._pyfn = None
         self._set_builtin_celltype(kind)
+
+    def set_box_faces(self, faces):
+        """The box with these six face types on every level (None: back to the all-Dirichlet box)."""
+        self._cb = self._pyfn = None
+        self._set_box_faces((C.c_int * 6)(*faces) if faces is not None else None)
 
     def level_cells(self, shape):
         """The byte map of a grid under the active cell rule, as the cycle drivers see it."""

@@ -177,6 +177,37 @@ def test_513_cubed_f32_cycle_matches_oracle(dev, mgo):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+def test_1025_cubed_f64_cycle_matches_oracle(dev, mgo):
+    """The largest configuration at full size: one V(2,2) cycle at 1025^3 in double (planes with more tiles than
+    the device runs at once, swept band by band; residual + restriction as one march) against the CPU oracle,
+    bit for bit.  About 60 GB of host memory and half a minute."""
+    f, ref = oracle_cycle(mgo, (1025, 1025, 1025), np.float64)
+    got = gpu_cycle(dev, f, use_graph=True)
+    assert np.array_equal(got.view(np.uint64), ref.view(np.uint64))
+
+
+@pytest.mark.parametrize("name", ["2d4097mixed", "3d257neumann", "2d257"])
+def test_benchmark_configurations_with_their_faces_match_oracle(dev, mgo, name):
+    """The benchmark's remaining workloads as bench.py sets them up (problem, faces, full z range), two V(2,2)
+    cycles at full size against the CPU oracle, bit for bit: 4097^2 with Dirichlet x faces and frozen Neumann y
+    faces, 257^3 with every face Neumann, 257^2."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    shape, dt, faces, problem, _ = bench.CONFIGS[name]
+    npdt = np.float32 if dt == "f32" else np.float64
+    mgo.set_box_faces(faces)
+    try:
+        f, _ = mgo.discretize(problem, shape, npdt)
+        ref = np.zeros(shape, npdt)
+        mgo.mg(ref, f, npdt(1.0), 2, 2, 1, 2, True)
+    finally:
+        mgo.set_box_faces(None)
+    got = gpu_cycle(dev, f, cycles=2, use_graph=True, faces=faces)
+    assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+    assert np.abs(ref).max() > 0
+
+
 def test_257_cubed_ball_domain_matches_oracle(dev, mgo):
     """A domain that is not a box, at 257^3: the ball inscribed in the cube with a Dirichlet /
     Neumann shell and outer cells around it, described by one byte per point on every level."""

@@ -66,12 +66,28 @@ def test_problem_setup_matches_golden(mgo, path):
 
 
 def test_known_answers_2d_257(mgo):
-    """The residual history the survey recorded for the 2D 257^2 Dirichlet V(2,2) float case."""
+    """Known answers: the residual history of the 2D 257^2 Dirichlet V(2,2) float case (the reference's kernels run serially
+    on the CPU before this tree existed), first six entries."""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "2d_257_f32_v22.npz"))
     expect = [8.282931639e+01, 2.989080772e+00, 7.839347357e-02, 2.326151235e-03, 9.590241536e-05, 4.229104532e-05]
     assert np.allclose(g["history"][:6], expect, rtol=5e-10, atol=0)
     hist, _, _ = run_case(mgo, g)
     assert np.allclose(hist[:6], expect, rtol=5e-10, atol=0)
+
+
+@pytest.mark.parametrize("shape", [(9, 17), (5, 9, 17)], ids=["2D", "3D"])
+def test_box_rule_with_face_types_equals_the_painted_map(mgo, shape):
+    """set_box_faces (the rule the cycle drivers use for the benchmark's Neumann configurations) against
+    box_cells, which paints the faces in the order of genBuffer (rectangularborderhandler.cpp:59-62,103-108):
+    same bytes, shared edges included."""
+    faces = (_oracle.DIRICHLET, _oracle.NEUMANN, _oracle.NEUMANN, _oracle.DIRICHLET, _oracle.DIRICHLET, _oracle.NEUMANN)
+    mgo.set_box_faces(faces)
+    try:
+        got = mgo.level_cells(shape)
+    finally:
+        mgo.set_box_faces(None)
+    assert np.array_equal(got, mgo.box_cells(shape, faces))
+    assert np.array_equal(mgo.level_cells(shape), mgo.box_cells(shape))
 
 
 def random_cells(lib, rng, shape):
