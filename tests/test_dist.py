@@ -77,6 +77,9 @@ GPU_CASES = [
     (2, (9, 641, 513), "f64", 1.0, 2, 2, 1, 2, True, 5 * 321 * 257),
     (3, (9, 961, 321), "f64", 0.9, 2, 2, 2, 1, True, 5 * 481 * 161),
     (2, (9, 641, 513), "f32", 1.0, 0, 2, 1, 2, True, 5 * 321 * 257),
+    # slabs whose planes have more tiles than the device runs at once: the fused sweeps go band by band
+    (2, (9, 1281, 1025), "f64", 1.0, 2, 2, 1, 2, True, 5 * 641 * 513),
+    (2, (9, 1281, 1025), "f32", 0.9, 2, 2, 1, 1, True, 5 * 641 * 513),
 ]
 
 
