@@ -606,7 +606,7 @@ def main():
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(args.config, shape)
         if world > 1 and os.environ.get("MGRT_BENCH_ATTEMPT"):  # every region of this line comes from this attempt
-            out["config"]["attempt"] = ATTEMPTS[int(os.environ["MGRT_BENCH_ATTEMPT"])][0]
+            out["config"]["attempt"] = "rehearsal" if rehearse else ATTEMPTS[int(os.environ["MGRT_BENCH_ATTEMPT"])][0]
         if os.environ.get("MGRT_BENCH_EARLIER"):
             out["config"]["attempts_that_failed"] = os.environ["MGRT_BENCH_EARLIER"]
         print(json.dumps(out), flush=True)
