@@ -51,13 +51,6 @@ enum Input { FIELD, ZEROS, CORRECTED };
 // weighs the residuals around it.  Whole grids with odd extents: the tile interiors then start on
 // even rows and columns, so every coarse point lies in exactly one of them, and a coarse point
 // injects exactly when it lies on a face.
-// 0.25 * s as the reference's single-precision build reads it (mg_0.cl:38: the literal makes the product double,
-// the assignment rounds it to float).  A quarter of a float is exact in double, so that is the exact quotient
-// rounded once -- which is what the single-precision product is, for every one of the 2^32 inputs, subnormal
-// results, infinities and NaN payloads included (tools/div6_exhaustive.c, column Q; the GPU test-suite runs all
-// inputs through both forms on the device).  One instruction instead of convert, multiply, convert.
-__device__ __forceinline__ float quarter(float s) { return 0.25f * s; }
-__device__ __forceinline__ double quarter(double s) { return 0.25 * s; }
 
 template <class R, int ITERS, int RT, bool OMEGA1, Input IN, int RES>
 __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN == CORRECTED ? RT + 8 : 0) + (RES == 2 ? 12 : 0)>())) void k_smooth2d_cols(
@@ -164,7 +157,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN ==
                     relax = mine && x_inner && j >= lo && j < hi;
                     fixed = mine && ((x_dirichlet && j >= fst && j <= lst) || (x_inner && (j == dlo || j == dhi)));
                 }
-                const R val = quarter(from_upper_lane(u[j]) + from_lower_lane(u[j]) + u[j + 1] + u[j - 1] - b[j]);
+                // mg_0.cl:38: 0.25 is a double literal, the assignment rounds to R.  A quarter of a float is exact in double, so
+                // for 4-byte elements this is the exact quotient rounded once, which is what the single-precision product is
+                // for every input (tools/div6_exhaustive.c, column Q; the compiler makes that product of it by itself).
+                const R val = 0.25 * (from_upper_lane(u[j]) + from_lower_lane(u[j]) + u[j + 1] + u[j - 1] - b[j]);
                 // for omega == 1 the double expression reduces exactly to val + 0*u evaluated in R
                 // (the product keeps the sign of a zero result and a non-finite u as the reference does)
                 R gs;
@@ -172,6 +168,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN ==
                     gs = val + (R)0 * u[j];
                 else
                     gs = val * omega + (1.0 - omega) * u[j];
+                // Keep the update unconditional (4-byte elements; with 8-byte ones the registers it takes spill): left
+                // alone, the compiler sinks it under branches on relax, and the exec-mask blocks that result cost more
+                // than the updates they skip (4097^2: 88 -> 75 us a sweep with residual and restriction).
+                if constexpr (sizeof(R) == 4)
+                    asm("" : "+v"(gs));
                 u[j] = relax ? gs : fixed ? b[j] : u[j];
             }
         }
