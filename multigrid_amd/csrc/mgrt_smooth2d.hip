@@ -126,7 +126,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN ==
                 const R ww = 0.5 * ((j + P) % 2);
                 const bool border = x_face ? x_border : (j == jlo - 1 && lo_border) || (j == jhi && hi_border);
                 const R n0 = (1.0 - wu) * (1.0 - ww), n1 = (1.0 - ww) * wu, n2 = (1.0 - wu) * ww, n3 = ww * wu;
-                const R val = border ? c0[k] : c0[k] * n0 + c1[k] * n1 + c0[k + 1] * n2 + c1[k + 1] * n3;
+                R interp = c0[k] * n0 + c1[k] * n1 + c0[k + 1] * n2 + c1[k + 1] * n3;
+                if constexpr (sizeof(R) == 4)
+                    asm("" : "+v"(interp)); // formed for every row: a branch on `border` per row costs more than the sum
+                const R val = border ? c0[k] : interp;
                 u[j] = u[j] + val * 4;
             }
         };
