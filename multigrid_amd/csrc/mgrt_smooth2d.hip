@@ -206,7 +206,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN ==
             const R xp = from_upper_lane(u[j]), xm = from_lower_lane(u[j]); // all lanes take part
             const bool inner = x_inner && j >= lo && j < hi;
             const bool dirichlet = (x_dirichlet && j >= first && j <= last) || (x_inner && (j == dlo || j == dhi));
-            const R v = inner ? b[j] - (xp + xm + u[j + 1] + u[j - 1] - 4 * u[j]) : dirichlet ? b[j] - u[j] : (R)0;
+            R vin = b[j] - (xp + xm + u[j + 1] + u[j - 1] - 4 * u[j]);
+            if constexpr (sizeof(R) == 4)
+                asm("" : "+v"(vin)); // formed for every row, like the update
+            const R v = inner ? vin : dirichlet ? b[j] - u[j] : (R)0;
             if constexpr (RES == 1) {
                 if (stores && j <= last)
                     *pr = v;
@@ -225,7 +228,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN ==
                 const R bm = from_lower_lane(b[j + 1]), bp = from_upper_lane(b[j + 1]);
                 const R cm = from_lower_lane(b[j]), cp = from_upper_lane(b[j]);
                 // mg_0.cl:152-156 with c = the fine point under the coarse one
-                const R w = 1.0 / 16.0 * (am + ap + bm + bp) + 1.0 / 8.0 * (b[j - 1] + cp + cm + b[j + 1]) + 1.0 / 4.0 * (b[j]);
+                R w = 1.0 / 16.0 * (am + ap + bm + bp) + 1.0 / 8.0 * (b[j - 1] + cp + cm + b[j + 1]) + 1.0 / 4.0 * (b[j]);
+                if constexpr (sizeof(R) == 4)
+                    asm("" : "+v"(w));
                 const bool face = x_face || j == jlo - 1 || j == jhi;
                 if (coarse_lane && j <= last)
                     pc[cg.pitch * (long long)((y0 + j) >> 1)] = face ? b[j] : w;
