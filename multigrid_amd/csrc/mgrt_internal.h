@@ -106,9 +106,14 @@ inline bool correct_sweep_3d_supported(const mgrt_grid *g, size_t elem, int iter
 {
     // from 100^2 columns up: below that the coarse loads lengthen the march by more than the correction's own
     // launch costs (65^3: 42 us against 35 + 6)
-    return g->dim == 3 && elem == 4 && iters == 2 && !g->cells && g->y0 % 2 == 0 && g->nx % 2 == 1 && g->gny % 2 == 1 &&
-           g->nz % 2 == 1 && g->nz >= 5 && (long long)g->nx * g->ny >= 100LL * 100LL && plane_offsets_fit(g, elem) &&
-           !neumann_extension(g);
+    // 8-byte elements: tiles of twelve two-row strips, and only where the plane has more four-row tiles (56 x 24 points
+    // of their own) than the device has CUs.  There the sweeps run at the rate of memory and the correction they spare
+    // is a whole read and write of the field (1025^3: 7.0 ms against 3.9 + 6.3); on smaller planes the sweep is bound
+    // by what a SIMD issues, and the narrow tiles cost more than the correction (513^3: 1.31 against 0.46 + 0.75 ms).
+    const bool wide8 = elem == 8 && (long long)((g->nx + 55) / 56) * ((g->ny + 23) / 24) > runtime().num_cu;
+    return g->dim == 3 && (elem == 4 || wide8) && iters == 2 && !g->cells && g->y0 % 2 == 0 &&
+           g->nx % 2 == 1 && g->gny % 2 == 1 && g->nz % 2 == 1 && g->nz >= 5 && (long long)g->nx * g->ny >= 100LL * 100LL &&
+           plane_offsets_fit(g, elem) && !neumann_extension(g);
 }
 
 // Whether mgrt_smooth_sweep_residual_restrict has a 3D kernel for this level (the restriction carried in

@@ -943,8 +943,8 @@ mgrt_status correct_smooth_sweep(const mgrt_grid *fine, const mgrt_grid *coarse,
         MGRT_REQUIRE(coarse->nz == (fine->nz + 1) / 2, "mgrt_correct_smooth_sweep: coarse grid has %d planes for %d",
                      coarse->nz, fine->nz);
         if (!correct_sweep_3d_supported(fine, sizeof(R), iters))
-            return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: in 3D, 4-byte elements, iters == 2, odd extents, an "
-                                            "even slab offset and at least 100^2 columns only");
+            return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: in 3D, iters == 2, odd extents, an even slab offset and "
+                                            "at least 100^2 columns (8-byte elements: planes of more tiles than the device has CUs) only");
         if constexpr (sizeof(R) == 4) {
             using C = Cfg<R>;
             // the shapes of the plain sweep on each kind of level, two planes prefetched
@@ -955,6 +955,15 @@ mgrt_status correct_smooth_sweep(const mgrt_grid *fine, const mgrt_grid *coarse,
             if (two_stage_six_strips(*fine))
                 return launch<R, 1, 2, 6, 2, false, true, 2>(fine, out, u, f, omega, zcount, (hipStream_t)s, nullptr, coarse, e);
             return launch<R, 1, 2, 8, 2, false, true, 2>(fine, out, u, f, omega, zcount, (hipStream_t)s, nullptr, coarse, e);
+        }
+        if constexpr (sizeof(R) == 8) {
+            // 8-byte elements, planes swept at the rate of memory: strips of two rows, twelve a tile (with four-row
+            // strips the coarse values are a hundred registers too many).  The tile has 16 rows of its own in 24 where
+            // the plain sweep has 24 in 32, but the separate correction it spares reads and writes the whole field
+            // once more.  The one kernel here that the compiler gives scratch memory (24-28 registers of 168): its
+            // spill traffic never touches a register with a load pending (tools/check_hidden_loads.py models the
+            // counter with the scratch operations in it), and it is faster with them than the two launches it replaces.
+            return launch<R, 2, 2, 12, 2, false, true>(fine, out, u, f, omega, zcount, (hipStream_t)s, nullptr, coarse, e);
         }
         return fail(MGRT_E_UNSUPPORTED, "mgrt_correct_smooth_sweep: no 3D kernel for this element size");
     }

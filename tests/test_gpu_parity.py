@@ -926,8 +926,14 @@ def test_large_planes_swept_in_bands_match_oracle_and_one_launch(dev, mgo, dt):
     assert bits_equal(run(lambda: with_restriction(0))[0], want_c)
     if L.restrict_sweep_supported(g, tdt, 2):
         run(lambda: with_restriction(2))
-    if L.correct_sweep_supported(g, tdt, 2):
-        run(corrected)
+    # the sweep on u + 4*P(e): single precision, and double precision on planes of this size (tiles of two-row strips)
+    assert L.correct_sweep_supported(g, tdt, 2)
+    ref = np.empty(shape, dt)
+    mgo.correct(cell, ref, u, e)
+    for _ in range(2):
+        for odd in (0, 1):
+            mgo.smooth_pass(cell, ref, f, dt(1.0), odd, None)
+    assert bits_equal(run(corrected)[0], ref)
 
     pshape = (9, 1025, 1025)
     pf = rng.standard_normal(pshape).astype(dt)
