@@ -167,9 +167,10 @@ int mgrt_last_sweep_launches(void);
     /* out = S^iters(u + 4*P(e)): the results of mgrt_correct followed by mgrt_smooth_sweep, the   \
        corrected field never written.  Replaces correct_residual followed by the post-smoothing    \
        smoother_iterate (multigridsolver2D.cpp:77,92, multigridsolver3D.cpp:70,77).  Analytic-box  \
-       grids with odd extents; in 3D only 4-byte elements, iters == 2, an even y0 and at least    \
-       100*100 columns (MGRT_E_UNSUPPORTED otherwise: call the two kernels).  out must not alias   \
-       an input. */                                                                                \
+       grids with odd extents; in 3D only iters == 2, an even y0 and at least 100*100 columns,     \
+       with 8-byte elements only planes of more tiles than the device has compute units            \
+       (MGRT_E_UNSUPPORTED otherwise: call the two kernels; mgrt_correct_smooth_sweep_supported    \
+       answers beforehand).  out must not alias an input. */                                       \
     mgrt_status mgrt_correct_smooth_sweep##S(const mgrt_grid *fine, const mgrt_grid *coarse,       \
                                              R *out, const R *u, const R *e, const R *f, R omega,  \
                                              int iters, int zcount, mgrt_stream s);                \
