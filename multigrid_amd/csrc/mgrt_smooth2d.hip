@@ -151,6 +151,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN ==
             const int fst = per_pass(first), lst = per_pass(last);
 #pragma unroll
             for (int j = 1; j < RT - 1; ++j) {
+                // every pass makes one more ring of the tile's halo worthless: pass number p (from 0) is only owed
+                // rows p + 1 .. RT - 2 - p, the others cannot reach a row that is stored (a uniform branch a row)
+                if (j < 1 + pass || j > RT - 2 - pass)
+                    continue;
                 const bool mine = (j & 1) ? !mine_even : mine_even;
                 bool relax, fixed;
                 if constexpr (decltype(inner_rows)::value) {
