@@ -53,7 +53,14 @@ __global__ __launch_bounds__(NW * 2 * kWave) void k_smooth3d_fused_pair(mgrt_gri
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);
-    const int stage = wave / NW, w = wave % NW;
+    // Which strip a wavefront takes.  The passes a strip sits out (below) leave the edge strips with less to do, and a
+    // time step lasts as long as the busiest SIMD; wavefront i of a block runs on SIMD i % 4, so the strips are dealt
+    // such that every SIMD gets the same number of colour passes a step (NW = 8: 6 of 8, NW = 6: 4 of 6).  Four bits a
+    // wavefront; the first NW wavefronts are the first stage.  A speed matter only: any bijection gives the same values.
+    static_assert(NW == 6 || NW == 8, "strip tables");
+    constexpr unsigned long long kStrips = NW == 8 ? 0x6543'1702'6427'5310ull  // 0 1 3 5 7 2 4 6 | 2 0 7 1 3 4 5 6
+                                                   : 0x0000'3250'4142'5031ull; // 1 3 0 5 2 4 | 1 4 0 5 2 3
+    const int stage = wave / NW, w = (int)((kStrips >> (4 * wave)) & 15u);
     const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tx = tile % ntx, ty = tile / ntx;
     const int x = tx * OX - H + lane;
@@ -106,6 +113,12 @@ __global__ __launch_bounds__(NW * 2 * kWave) void k_smooth3d_fused_pair(mgrt_gri
         constexpr int kLoads = FIRST ? 8 : 0;       // vector-memory operations a fast step issues
         constexpr int kYounger = (PD - 1) * kLoads;             // ... after the loads of the slot being waited for
         static_assert(kYounger < 64, "too many vector-memory operations in flight for a counted wait");
+        bool pass_needed[2];
+#pragma unroll
+        for (int d = 1; d <= 2; ++d) {
+            const int P = 2 * STG + d;
+            pass_needed[d - 1] = 2 * w + 1 >= P && 2 * w <= 2 * NW - 1 - P;
+        }
         R C[2][ND], F[2][ND];
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -217,6 +230,11 @@ __global__ __launch_bounds__(NW * 2 * kWave) void k_smooth3d_fused_pair(mgrt_gri
                     for (int d = 1; d <= 2; ++d) {
                         const int c = d - 1;
                         const bool sc = (s0 ^ c) != 0; // the lower row of the pair holds the colour-c point
+                        // Every colour pass makes one more ring of the tile's halo worthless: pass number P of the four
+                        // (two a stage) is owed rows P .. 2*NW - 1 - P only, nothing that is stored can depend on the
+                        // others.  A strip with neither of its rows in that range sits the pass out (wave-uniform).
+                        if (!pass_needed[d - 1])
+                            continue;
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const int dep = 2 * d + 1 - q, z = 2 * k + 1 - dep;
