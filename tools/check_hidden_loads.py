@@ -46,6 +46,7 @@ def main():
             subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
             text += open(out).read().splitlines()
     kernel, bad, nk, loops = None, [], 0, 0
+    per_kernel = {}
     in_asm, depth2 = False, False
     loop_lines = []
 
@@ -58,6 +59,7 @@ def main():
         if not loop_lines:
             return
         loops += 1
+        per_kernel[kernel] = per_kernel.get(kernel, 0) + 1
         queue, pending, seen = [], set(), set()
         for _ in range(2):
             for asm, line in loop_lines:
@@ -134,6 +136,9 @@ def main():
             if name and int(m.group(1)) > 0 and not SCRATCH_ALLOWED.search(name):
                 bad.append((name, "uses %s bytes of scratch memory per lane" % m.group(1)))
             name = None
+    if os.environ.get("MGRT_AUDIT_VERBOSE"):
+        for k, n in sorted(per_kernel.items()):
+            print("check_hidden_loads: %d inner loop(s) in %s" % (n, k[:110]))
     if nk == 0 or loops == 0:
         print("check_hidden_loads: found %d kernels, %d inner loops -- the audit did not run" % (nk, loops))
         return 1
