@@ -477,7 +477,7 @@ def main():
             alg_bytes = 3.0 * dof * w  # read u, read f, write the smoothed field
             kernel = ("k_smooth3d_fused", "3D sweep of 2 red-black iterations")
             fields = {0: "float" if w == 4 else "double", 1: "2", 5: "true", 6: "false", 7: "false"}
-            if w == 4 and 100 * 100 <= shape[1] * shape[2] <= 300 * 300:
+            if w == 4 and 60 * 60 <= shape[1] * shape[2] <= 300 * 300:
                 # latency-bound level: two stages of one iteration each, two planes a time step
                 kernel = ("k_smooth3d_fused_pair", kernel[1] + " (two stages, two planes a step)")
                 fields = {0: "float", 3: "true"}

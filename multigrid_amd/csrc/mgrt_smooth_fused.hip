@@ -925,7 +925,9 @@ mgrt_status smooth_sweep(const mgrt_grid *g, R *out, const R *in, const R *f, R 
     if (small) {
         const bool six = two_stage_six_strips(*g), wide = (long long)g->nx * g->ny >= 100LL * 100LL;
         if constexpr (sizeof(R) == 4) {
-            if (wide) // below that its longer lag costs what its shorter steps gain (33^3: 18 against 16 us)
+            // from 60^2 columns up; below that its longer lag costs what its shorter steps gain (65^3: 25.3 against
+            // 27.0 us, 33^3: 17.6 against 17.0)
+            if ((long long)g->nx * g->ny >= 60LL * 60LL)
                 return smooth_sweep_pair(g, out, in, f, omega, zcount, six, hs);
         }
         if (!six)
