@@ -188,14 +188,17 @@ mgrt_status iterate(mgrt_plan *p, int l, R *u, const R *f, R omega, int a1, int 
     // On bandwidth-bound levels the last pre-smoothing sweep carries the residual pass along
     // (4-byte elements: with 8-byte ones the narrower strips make it slower than the two kernels).
     // In 2D every fused level does.  The last correction goes into the first post-smoothing sweep
-    // where a kernel for that exists: every 2D level, and in 3D the bandwidth-bound levels in single
-    // precision when that sweep does two iterations.
+    // where a kernel for that exists and pays: every 2D level, and in 3D the bandwidth-bound levels when that
+    // sweep does two iterations (double precision: only planes of more tiles than the device has CUs).
     const bool res_in_sweep =
         n1 > 0 && v > 0 && recurses(L.g) &&
         (L.g.dim == 2 || (sizeof(R) == 4 && L.g.dim == 3 && !latency_bound_level(L.g) && !L.g.cells));
     const bool correct_in_sweep =
         n2 > 0 && a2 > 0 && v > 0 && recurses(L.g) &&
-        (L.g.dim == 2 || correct_sweep_3d_supported(&L.g, sizeof(R), n2 < a2 ? 2 : 1));
+        (L.g.dim == 2 || (correct_sweep_3d_supported(&L.g, sizeof(R), n2 < a2 ? 2 : 1) && !latency_bound_level(L.g)));
+    // (On latency-bound levels the plain sweep takes two planes a time step, which the sweep on the corrected field
+    // cannot, for registers: correction + sweep is the faster pair there, 257^3: 26 + 87 against 115 us, 129^3: 7 + 41
+    // against 56.)
     // That sweep hands the coarse level its right-hand side directly where a kernel for it exists: every 2D
     // level, and in 3D the bandwidth-bound levels in single precision when it does two iterations (the
     // fine residual is then written next to the seams between rows of tiles only).
