@@ -69,6 +69,7 @@ struct CoarseField {
     long long pitch, slab;
     int nx, ny, nz, y0;
     int ylo, yhi;  // RST: the coarse rows (of the coarse array) this launch writes
+    int kchunk;    // RST without smoothing: coarse planes a block forms (blockIdx.y counts the chunks); 0: all of them
 };
 
 // dot(real4, real4) as the reference evaluates it: left to right in R
@@ -255,6 +256,20 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     const int zlast = g.nz - 1;
     const int zlim = zcount < g.nz ? zcount : g.nz;
     const int wu = w > 0 ? w - 1 : 0, wd = w + 1 < NW ? w + 1 : NW - 1;
+    // Residual and restriction without smoothing have no recurrence in z, so the march can be cut: the block with
+    // blockIdx.y = b forms coarse planes [K0, K1) only.  It starts at fine plane zs (the residual of plane 2*K0 - 1 is
+    // the first it needs: planes from 2*K0 - 2 on, rounded down to the unrolled loop) and writes the seam rows of the
+    // residual planes [2*K0, 2*K1), so that every plane of r has one writer; what it computes for other planes (from
+    // the incomplete ring at its start, in the rest of its last group of steps) goes to a descriptor of length 0.
+    constexpr bool CHUNKS = RST && ITERS == 0;
+    int K0 = 0, K1 = cf.nz, zs = 0;
+    if constexpr (CHUNKS) {
+        if (cf.kchunk > 0) {
+            K0 = (int)blockIdx.y * cf.kchunk;
+            K1 = K0 + cf.kchunk < cf.nz ? K0 + cf.kchunk : cf.nz;
+            zs = K0 > 0 ? (2 * K0 - 2) & ~(UN - 1) : 0;
+        }
+    }
 
     auto march = [&](auto stage_tag) {
     constexpr int STG = decltype(stage_tag)::value;
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     if constexpr (FIRST) {
 #pragma unroll
         for (int k = 0; k < PD; ++k) {
-            const long long zo = slab * (k < zlast ? k : zlast);
+            const long long zo = slab * (zs + k < zlast ? zs + k : zlast);
             const desc_t ru = plane_desc(inb + zo, in_bytes), rf = plane_desc(f + zo, plane_bytes);
 #pragma unroll
             for (int r = 0; r < SR; ++r) {
@@ -385,7 +400,8 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
 
     // planes entering this stage's ring: the last one finishes plane nz-1; all stages together take
     // nsteps_all time steps, every one of them with a barrier that every wavefront of the block joins
-    const int nsteps = g.nz + (RST ? DR + 2 : RES ? DR : NP); // RST: the last coarse plane follows two steps later
+    // (a chunk: coarse plane K1 - 1 is stored in step 2*K1 + 2)
+    const int nsteps = CHUNKS ? 2 * K1 + 3 : g.nz + (RST ? DR + 2 : RES ? DR : NP); // RST: the last coarse plane follows two steps later
     const int nsteps_all = nsteps + (STAGES - 1) * LAG;
     // One group of UN consecutive time steps, unrolled so that every ring index is a constant.
     // FAST groups are those whose steps all work on planes strictly between the z faces and below
@@ -639,7 +655,9 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                     const int zc = i - 2 - DR; // centre plane
                     if (((u + 1 + DR) & 1) != 0 && (FAST || (zc >= 0 && zc <= zlast))) {
                         const bool zface = zc <= 0 || zc >= zlast;
-                        const desc_t rd = FAST ? d_rc : plane_desc(rcb + cf.slab * (zc / 2), rcplane_bytes);
+                        desc_t rd = FAST ? d_rc : plane_desc(rcb + cf.slab * (zc / 2), rcplane_bytes);
+                        if (CHUNKS && !(zc >= 2 * K0 && zc < 2 * K1))
+                            rd.z = 0; // not this chunk's plane: a descriptor of length 0 drops the stores
 #pragma unroll
                         for (int j = 0; j < J; ++j) {
                             // planes z+ (P), z (Z), z- (M); colour 0 (A) holds the rows of the coarse points on
@@ -695,7 +713,9 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                                 rv[c][j] = is_in ? vi : (is_dir ? vd : (R)0);
                             }
                         }
-                        const desc_t rr = FAST ? d_res : plane_desc(res + slab * z, plane_bytes);
+                        desc_t rr = FAST ? d_res : plane_desc(res + slab * z, plane_bytes);
+                        if (CHUNKS && !(z >= 2 * K0 && z < 2 * K1))
+                            rr.z = 0; // as for the coarse plane above
                         if constexpr (RST) {
                             // keep the plane, hand its first pair to the strip above, write the seam rows
 #pragma unroll
@@ -754,6 +774,8 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     // step: shallowest plane i0 + UN - 2 below the top face and zlim, prefetched plane
     // i0 + UN - 1 + PD <= zlast
     auto is_fast = [&](int i0) {
+        if (CHUNKS && i0 >= nsteps)
+            return false; // the chunk ends here
         return i0 >= (RES ? DR : NP) + 1 && i0 + UN - 2 < zlim && i0 + UN - 2 < zlast &&
                i0 + UN - 1 + PD + (COR ? 2 : 0) <= zlast; // COR: the coarse plane above the prefetched fine one exists
     };
@@ -763,7 +785,7 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
     // forces a full vmcnt(0) drain per group).
     // Every wavefront of the block walks the same sequence of groups (one barrier per time step each);
     // whether a group is a fast one is each stage's own matter.
-    for (int g0 = 0; g0 < nsteps_all;) {
+    for (int g0 = zs; g0 < nsteps_all;) {
         if (is_fast(g0 - lag)) {
             do {
                 group(std::true_type{}, g0);
@@ -793,7 +815,7 @@ template <class R, int ITERS, int SR, int NW, int PD, bool RES = false, bool COR
           bool RST = false>
 mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega, int zcount, hipStream_t hs,
                    R *res = nullptr, const mgrt_grid *cg = nullptr, const R *e = nullptr, R *rc = nullptr, int cylo = 0,
-                   int cyhi = 1 << 30)
+                   int cyhi = 1 << 30, int kchunk = 0)
 {
     constexpr int H = 2 * ITERS * STAGES + (RES ? 1 : 0), OX = kWave - 2 * (H + (RST ? 1 : 0)), OY = NW * SR - 2 * H;
     static_assert(OY > 0, "tile has no interior");
@@ -806,7 +828,9 @@ mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega,
         cf.e = e, cf.rc = rc, cf.pitch = cg->pitch, cf.slab = cg->slab;
         cf.nx = cg->nx, cf.ny = cg->ny, cf.nz = cg->nz, cf.y0 = cg->y0;
         cf.ylo = cylo > 0 ? cylo : 0, cf.yhi = cyhi < cg->ny ? cyhi : cg->ny;
+        cf.kchunk = RST && ITERS == 0 ? kchunk : 0;
     }
+    const int nchunks = cf.kchunk > 0 ? (cf.nz + cf.kchunk - 1) / cf.kchunk : 1; // blocks along z
     // A plane with more tiles than the part runs at once is swept band by band, each band a launch of whole tile rows
     // that all start together.  In one launch the tiles of the later rounds start whenever a CU falls free, at z = 0 beside
     // neighbours that are hundreds of planes further on, and no halo row or column is found in the L2 any more
@@ -830,7 +854,7 @@ mgrt_status launch(const mgrt_grid *g, R *out, const R *in, const R *f, R omega,
     runtime().last_sweep_launches = 0;
     for (int ty0 = 0; ty0 < nty; ty0 += band_rows) {
         const int rows = nty - ty0 < band_rows ? nty - ty0 : band_rows;
-        kernel<<<dim3(ntx * rows), NW * STAGES * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, nty, ty0, cf);
+        kernel<<<dim3(ntx * rows, nchunks), NW * STAGES * kWave, 0, hs>>>(*g, in, out, f, res, omega, zcount, ntx, nty, ty0, cf);
         ++runtime().last_sweep_launches;
     }
     MGRT_HIP(hipGetLastError());
@@ -1061,6 +1085,24 @@ mgrt_status smooth_sweep_residual_restrict(const mgrt_grid *fine, const mgrt_gri
             // kernels, the residual passing through r (257^3: 39 + 14 us against 100 for a march)
             if ((long long)fine->nx * fine->ny < 100LL * 100LL)
                 return residual_restrict_tiles(fine, coarse, rc, in, f, hs);
+            // ... as long as r stays in the last-level cache between the two.  A residual field of more than about
+            // 100 MB does not (257^3 in double precision: 151 us for the two kernels, 2.8 times the 53 us of single
+            // precision), and there the march wins once it is cut along z into as many chunks of coarse planes as
+            // leave every block a CU of its own (no recurrence in z without smoothing): 92 us, bit for bit the same.
+            // Where r does stay in cache it is no faster (257^3 float 53.5 against 53.0 us, 193^3 double 47.5
+            // against 47.7).
+            if ((long long)fine->nx * fine->ny * fine->nz * (long long)sizeof(R) > (96LL << 20)) {
+                oy = 32 - 2;
+                const int tiles = ((fine->nx + 59) / 60) * ((fine->ny + oy - 1) / oy);
+                const int nchunks = runtime().num_cu / tiles > 1 ? runtime().num_cu / tiles : 1;
+                const int kchunk = (coarse->nz + nchunks - 1) / nchunks;
+                st = launch<R, 0, 4, 8, sizeof(R) == 4 ? 4 : 2, true, false, 1, false, true>(fine, nullptr, in, f, omega, zcount, hs, r, coarse,
+                                                                                             nullptr, rc, 0, 1 << 30, kchunk);
+                if (st != MGRT_OK)
+                    return st;
+                const int nseams = (fine->ny + oy - 1) / oy - 1;
+                return restrict_rows(fine, coarse, rc, r, oy / 2, oy / 2, nseams, hs);
+            }
             if (mgrt_status st2 = Step<R>::residual(fine, r, in, f, 1, nullptr, 0, fine->ny, s))
                 return st2;
             return Step<R>::restrict_(fine, coarse, rc, r, 0, coarse->ny, s);

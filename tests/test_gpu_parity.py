@@ -815,8 +815,11 @@ def test_plan_with_restriction_in_sweep_equals_separate_restriction(dev):
 
 # (nz, ny, nx): planes below and above the 300^2-column limit (strips of two and of four rows), tile row
 # seams (every 14 or 30 rows) that fall on the last grid row or leave a last tile row of one grid row, a
-# narrow last tile column, the smallest plane count
-RESRST_SHAPES = [(9, 29, 61), (5, 31, 63), (17, 45, 121), (7, 65, 65), (5, 331, 305), (9, 361, 303)]
+# narrow last tile column, the smallest plane count; the last two: residual fields of more than 96 MiB on at most
+# 300^2 columns (the first in double precision only), where the march is cut along z into chunks of 17 and of 29
+# coarse planes (chunk starts on both alignments of the loop unrolled over four planes)
+RESRST_SHAPES = [(9, 29, 61), (5, 31, 63), (17, 45, 121), (7, 65, 65), (5, 331, 305), (9, 361, 303), (257, 225, 225),
+                 (289, 295, 297)]
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64], ids=["f32", "f64"])
