@@ -673,7 +673,19 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                                             RB(3, j + 1) + RB(3, j) + UP(RB(3, j)) + LO(RB(3, j)) +
                                             RB(1, j + 1) + RB(1, j) + UP(RB(1, j)) + LO(RB(1, j));
                             const R faces = RB(2, j + 1) + RB(2, j) + UP(RB(2, j)) + LO(RB(2, j)) + RA(1, j) + RA(3, j);
-                            R val = 1.0 / 64.0 * corners + 1.0 / 32.0 * edges + 1.0 / 16.0 * faces + 1.0 / 8.0 * (RA(2, j));
+                            // The weights are powers of two, so with 4-byte elements every product is exact in double and
+                            // a fused multiply-add rounds what the reference's separate multiply and add round: the
+                            // same bits in four double-precision instructions instead of seven.  (8-byte elements keep
+                            // the separate form: there a product can fall into the subnormal range and round.)
+                            R val;
+                            if constexpr (sizeof(R) == 4) {
+                                double t = 1.0 / 64.0 * (double)corners;
+                                t = __builtin_fma((double)edges, 1.0 / 32.0, t);
+                                t = __builtin_fma((double)faces, 1.0 / 16.0, t);
+                                val = (R)__builtin_fma((double)RA(2, j), 1.0 / 8.0, t);
+                            } else {
+                                val = 1.0 / 64.0 * corners + 1.0 / 32.0 * edges + 1.0 / 16.0 * faces + 1.0 / 8.0 * (RA(2, j));
+                            }
                             asm("" : "+v"(val));
                             buf_store_hidden(injl[j] || zface ? RA(2, j) : val, rd, cof[j]);
 #undef RA
