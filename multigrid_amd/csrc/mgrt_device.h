@@ -50,6 +50,10 @@ __device__ __forceinline__ void buf_load(double &v, rsrc_t r, unsigned off)
 // hidden stores as well, so those waits are merely stricter than needed.  Nothing ever reads
 // `out` in this kernel, so the stores themselves need no wait.  The descriptor words come from
 // scalar ALU results, hence the wait states opening the string.
+// a*b + c with one rounding, in the type of the operands (the generic builtin would promote floats to double)
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 typedef int desc_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ desc_t plane_desc(const void *base, unsigned bytes)
 {

@@ -606,10 +606,11 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                             // mg_1.cl:35-42: neighbours summed in R in this order, times the
                             // double literal 1.0/6.0, rounded to R
                             const R val = (1.0 / 6.0) * (xp + xm + yp + ym + C[c][PH(d - 1)][j] + C[c][PH(d + 1)][j] - fv);
-                            // mg_1.cl:69; for omega == 1 the double expression reduces exactly
-                            // to val + 0*own evaluated in R (one fused multiply-add would give the
-                            // same bits, the product being exact, but measured 5 % slower per cycle)
-                            R gs = OMEGA1 ? val + (R)0 * own : (R)(val * omega + (1.0 - omega) * own);
+                            // mg_1.cl:69; for omega == 1 the double expression reduces exactly to val + 0*own
+                            // evaluated in R, and that to one fused multiply-add (the product, a zero or a NaN, is
+                            // exact, so the one rounding is that of the sum: same bits, v_fmac_f32 with the constant
+                            // inline)
+                            R gs = OMEGA1 ? fma_r((R)0, own, val) : (R)(val * omega + (1.0 - omega) * own);
                             // Keep the update unconditional: left alone, the compiler sinks it
                             // under a branch on take_gs, and the exec-mask blocks that result
                             // serialise the independent updates of a step and their LDS reads.

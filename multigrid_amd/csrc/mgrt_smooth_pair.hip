@@ -252,8 +252,8 @@ __global__ __launch_bounds__(NW * 2 * kWave) void k_smooth3d_fused_pair(mgrt_gri
                                 // mg_1.cl:35-42: neighbours summed in R in this order (z+1 old, z-1 new), times the
                                 // double literal 1.0/6.0, rounded to R
                                 const R val = (1.0 / 6.0) * (xp + xm + yp + ym + C[c][SL(dep - 1)] + C[c][SL(dep + 1)] - fv);
-                                // mg_1.cl:69; for omega == 1 the double expression reduces exactly to val + 0*own in R
-                                R gs = OMEGA1 ? val + (R)0 * own : (R)(val * omega + (1.0 - omega) * own);
+                                // mg_1.cl:69; for omega == 1 the double expression reduces exactly to val + 0*own in R: one fused multiply-add
+                                R gs = OMEGA1 ? fma_r((R)0, own, val) : (R)(val * omega + (1.0 - omega) * own);
                                 asm("" : "+v"(gs)); // keep the update unconditional (no exec-mask blocks)
                                 const bool take_gs = FAST ? interior[c] : (interior[c] && zin);
                                 const bool take_f = FAST ? latfix[c] : (interior[c] ? zdir : latdir[c]);
