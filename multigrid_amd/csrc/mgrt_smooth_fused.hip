@@ -622,7 +622,10 @@ __global__ __launch_bounds__(NW *STAGES *kWave) void k_smooth3d_fused(mgrt_grid 
                                 take_gs = cls == MGRT_CELL_INNER;
                                 take_f = cls == MGRT_CELL_DIRICHLET;
                             }
-                            C[c][PH(d)][j] = take_gs ? gs : (take_f ? fv : own);
+                            // From the second iteration on a lateral Dirichlet point already holds its f (the pass of the
+                            // first iteration put it there, bit for bit), so between the z faces one select is enough.
+                            const bool settled = FAST && !MAP && STG * NP + d > 2;
+                            C[c][PH(d)][j] = take_gs ? gs : (settled ? own : (take_f ? fv : own));
                         }
                     }
                 }

@@ -257,7 +257,9 @@ __global__ __launch_bounds__(NW * 2 * kWave) void k_smooth3d_fused_pair(mgrt_gri
                                 asm("" : "+v"(gs)); // keep the update unconditional (no exec-mask blocks)
                                 const bool take_gs = FAST ? interior[c] : (interior[c] && zin);
                                 const bool take_f = FAST ? latfix[c] : (interior[c] ? zdir : latdir[c]);
-                                C[c][SL(dep)] = take_gs ? gs : (take_f ? fv : own);
+                                // second stage: a lateral Dirichlet point already holds its f, bit for bit (the first
+                                // stage's pass put it there), so between the z faces one select is enough
+                                C[c][SL(dep)] = take_gs ? gs : (FAST && STG == 1 ? own : (take_f ? fv : own));
                             }
                         }
                     }
