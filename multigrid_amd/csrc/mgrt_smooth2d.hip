@@ -172,7 +172,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, (cols_waves<R, 2 * RT + (IN ==
                 // (the product keeps the sign of a zero result and a non-finite u as the reference does)
                 R gs;
                 if constexpr (OMEGA1)
-                    gs = fma_r((R)0, u[j], val); // one rounding, of the sum: the product is exact
+                    gs = sizeof(R) == 4 ? fma_r((R)0, u[j], val) // one rounding, of the sum: the product is exact
+                                        : val + (R)0 * u[j];     // (8-byte elements: the fused form makes the variants spill)
                 else
                     gs = val * omega + (1.0 - omega) * u[j];
                 // Keep the update unconditional (4-byte elements; with 8-byte ones the registers it takes spill): left
