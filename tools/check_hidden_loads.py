@@ -6,7 +6,9 @@ the kernel's own s_waitcnt.  The source guarantees this everywhere except inside
 This script compiles the file to assembly and fails if, inside any depth-2 loop of a
 k_smooth3d_fused kernel, a compiler-generated instruction reads a register that an asm load in
 that loop writes before a wait has retired that load (the counter is modelled: operations retire
-in issue order, vmcnt(N) leaves the youngest N in flight).
+in issue order, vmcnt(N) leaves the youngest N in flight).  Second check: no memory instruction from inline asm
+reads a scalar register (its descriptor) fewer than five wait states after a vector-ALU instruction wrote it -- the
+compiler pads its own memory instructions for that, but does not look inside asm (sgpr_hazards below).
 
 Usage: tools/check_hidden_loads.py [hipcc flags...]   (exit status 1 on a finding)"""
 import os
@@ -34,6 +36,97 @@ def regs(tok):
     if m:
         return set(range(int(m.group(1)), int(m.group(2)) + 1))
     return set()
+
+
+def sregs(tok):
+    """s12 or s[12:15] -> {12, ..., 15}"""
+    m = re.fullmatch(r"s(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def sgpr_hazards(text):
+    """A vector-memory instruction must not read a scalar register that a vector-ALU instruction wrote fewer than
+    five wait states earlier; the compiler pads its own memory instructions with s_nop, but it does not look inside
+    an asm block.  For every buffer instruction that comes from inline asm: walk back through up to five wait states
+    (an instruction is one, s_nop N is N + 1) along every path that leads there -- the fall-through and every branch
+    to a label on the way -- and report a v_ instruction whose scalar destination overlaps the descriptor."""
+    findings, kernel, ins, labels, in_asm = [], None, [], {}, False
+
+    def check_kernel():
+        targets = {}
+        for i, (txt, _) in enumerate(ins):
+            m = re.match(r"s_c?branch\w*\s+(\S+)", txt)
+            if m:
+                targets.setdefault(m.group(1), []).append(i)
+        label_at = {}
+        for name, pos in labels.items():
+            label_at.setdefault(pos, []).append(name)
+
+        def walk(i, budget, desc, seen, out):
+            """instructions before position i (exclusive)"""
+            while budget > 0:
+                for name in label_at.get(i, []):  # a label sits in front of instruction i: its other predecessors
+                    for b in targets.get(name, []):
+                        if (b, budget) not in seen:
+                            seen.add((b, budget))
+                            walk(b + 1, budget, desc, seen, out)
+                i -= 1
+                if i < 0:
+                    return
+                txt = ins[i][0]
+                op = txt.split()[0]
+                if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                    return  # nothing falls through from here
+                if op.startswith("v_"):
+                    ops = [o.strip() for o in txt[len(op):].split(",")]
+                    dst = ops[:2] if ("_co_" in op or op.startswith(("v_div_scale", "v_mad_u64", "v_mad_i64"))) else ops[:1]
+                    for d in dst:
+                        if sregs(d) & desc:
+                            out.append(txt)
+                m = re.match(r"s_nop\s+(\d+)", txt)
+                budget -= int(m.group(1)) + 1 if m else 1
+
+        for i, (txt, asm) in enumerate(ins):
+            if not asm:
+                continue
+            m = re.match(r"buffer_\w+\s+\S+,\s*\S+,\s*(s\[\d+:\d+\])", txt)
+            if not m:
+                continue
+            out = []
+            walk(i, 5, sregs(m.group(1)), set(), out)
+            for w in out:
+                findings.append((kernel, "%s   <- fewer than 5 wait states after   %s" % (txt, w)))
+
+    for line in text:
+        m = re.match(r"^(_Z\S*k_smooth3d_fused\S*):", line)
+        if m:
+            kernel, ins, labels = m.group(1), [], {}
+            continue
+        if kernel is None:
+            continue
+        if ";;#ASMSTART" in line:
+            in_asm = True
+            continue
+        if ";;#ASMEND" in line:
+            in_asm = False
+            continue
+        m = re.match(r"^(\.LBB\d+_\d+):", line)
+        if m:
+            labels[m.group(1)] = len(ins)
+            continue
+        t = line.split(";")[0].strip()
+        if not t or t.startswith(".") or t.endswith(":"):
+            continue
+        ins.append((t, in_asm))
+        if t.startswith("s_endpgm"):
+            check_kernel()
+            kernel = None
+    return findings
 
 
 def main():
@@ -136,6 +229,9 @@ def main():
             if name and int(m.group(1)) > 0 and not SCRATCH_ALLOWED.search(name):
                 bad.append((name, "uses %s bytes of scratch memory per lane" % m.group(1)))
             name = None
+    hazards = sgpr_hazards(text)
+    for k, l in hazards:
+        print("check_hidden_loads: %s: scalar-register hazard: %s" % (k[:70], l))
     if os.environ.get("MGRT_AUDIT_VERBOSE"):
         for k, n in sorted(per_kernel.items()):
             print("check_hidden_loads: %d inner loop(s) in %s" % (n, k[:110]))
@@ -144,8 +240,8 @@ def main():
         return 1
     for k, l in bad:
         print("check_hidden_loads: %s: use of a register with a hidden load pending: %s" % (k[:70], l))
-    print("check_hidden_loads: %d kernels, %d inner loops, %d findings" % (nk, loops, len(bad)))
-    return 1 if bad else 0
+    print("check_hidden_loads: %d kernels, %d inner loops, %d findings" % (nk, loops, len(bad) + len(hazards)))
+    return 1 if bad or hazards else 0
 
 
 if __name__ == "__main__":
