@@ -45,3 +45,30 @@ def test_2d_tile_kernels_do_not_spill(tmp_path):
             name = None
     assert seen >= 16, "no k_smooth2d_cols kernels found in the assembly"
     assert not bad, bad[:5]
+
+
+def test_scalar_register_hazard_check_finds_what_it_should():
+    """The audit's second check on synthetic listings: a vector-ALU write of a descriptor register fewer than five
+    wait states before a buffer instruction from inline asm is reported -- directly in front, across a branch to the
+    block of the instruction -- and not when s_nop pads it, when a scalar instruction wrote the register, or when the
+    buffer instruction is the compiler's own (which the compiler pads itself)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import check_hidden_loads as audit
+    finally:
+        sys.path.pop(0)
+
+    def listing(body):
+        return ["_ZN1x16k_smooth3d_fusedIfEEvv:"] + body + ["\ts_endpgm"]
+
+    store = ["\t;;#ASMSTART", "\tbuffer_store_dword v0, v1, s[8:11], 0 offen", "\t;;#ASMEND"]
+    assert len(audit.sgpr_hazards(listing(["\tv_readfirstlane_b32 s9, v3", "\tv_add_f32_e32 v0, v0, v0"] + store))) == 1
+    assert audit.sgpr_hazards(listing(["\tv_readfirstlane_b32 s9, v3", "\ts_nop 4"] + store)) == []
+    assert audit.sgpr_hazards(listing(["\tv_readfirstlane_b32 s12, v3"] + store)) == []
+    assert audit.sgpr_hazards(listing(["\ts_add_u32 s8, s8, s20", "\ts_addc_u32 s9, s9, s21"] + store)) == []
+    assert audit.sgpr_hazards(listing(["\tv_readfirstlane_b32 s9, v3", "\tbuffer_store_dword v0, v1, s[8:11], 0 offen"])) == []
+    # the write sits at the end of another block that branches to the store's block
+    across = ["\tv_cmp_lt_f32_e64 s[10:11], v0, v1", "\ts_cbranch_scc1 .LBB0_2", "\ts_nop 7", "\ts_branch .LBB0_3", ".LBB0_2:"] + store + [".LBB0_3:"]
+    assert len(audit.sgpr_hazards(listing(across))) == 1
+    # carry-out destinations count as well
+    assert len(audit.sgpr_hazards(listing(["\tv_add_co_u32_e64 v2, s[8:9], v2, v3"] + store))) == 1
